@@ -1,0 +1,194 @@
+/*
+ * simplexmethod_amd.h — C ABI of the MI355X-native dense-LP hot path.
+ *
+ * The reference (haskell-md2/SimplexMethod) has no FFI/plugin interface: its
+ * boundary is the C++ class API `Solver(const Canonical&)` + `solve()`
+ * (/root/reference/src/SimplexSolover.h:285-328) and, by README intent
+ * (README.md:27,40-42), the same shape for `EnumerationSolver`
+ * (src/EnumerationSolver.h:3-10, an empty stub).  The functions below are what a
+ * maintainer binds instead of the Eigen arithmetic inside those two classes; the
+ * C++ wrappers in simplexmethod_amd/host/ (Solver, EnumerationSolver) are that
+ * binding and keep the reference's names, arguments and exception behaviour.
+ * See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller allocates every output; no
+ *     ownership transfer; no exceptions cross the ABI.
+ *   - matrices are COLUMN-MAJOR fp64 (Eigen's default order, so the reference's
+ *     `A.data()` can be passed as is); indices are 32-bit int; combination ranks
+ *     are 64-bit unsigned.
+ *   - m = rows of the canonical A, n = ALL canonical columns (slacks included),
+ *     n_orig = Canonical::GetOriginalVariablesCount() (Canonical.cpp:151-154).
+ *   - every entry point returns one of the LP_* codes below; negative values are
+ *     HIP runtime failures (-(int)hipError_t); lp_last_error() has the text.
+ *   - there is NO CPU fallback: without a usable gfx950 device
+ *     lp_context_create fails and every other call needs a context.
+ */
+#ifndef SIMPLEXMETHOD_AMD_H
+#define SIMPLEXMETHOD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LP_ABI_VERSION 1
+
+/* Status codes; the C++ wrappers map them back to the
+ * reference's exception types and messages.                                     */
+enum {
+    LP_OPTIMAL = 0,     /* Solver::solve returned                  SimplexSolover.h:432-440 */
+    LP_UNBOUNDED = 1,   /* std::runtime_error, objective unbounded SimplexSolover.h:442-444 */
+    LP_ITER_LIMIT = 2,  /* std::runtime_error, iteration limit     SimplexSolover.h:450     */
+    LP_SINGULAR = 3,    /* std::runtime_error "Singular basis matrix"        :125-126       */
+    LP_INFEASIBLE = 4,  /* enumeration found no feasible basis                              */
+    LP_BAD_ARG = 5      /* std::invalid_argument from Canonical's ctor, Canonical.cpp:27-46;
+                           "basis index out of range", SimplexSolover.h:101                 */
+};
+
+/* Enumeration verdict for one basis subset. */
+enum { LP_SUBSET_FEASIBLE = 0, LP_SUBSET_INFEASIBLE = 1, LP_SUBSET_SINGULAR = 2 };
+
+typedef struct lp_context lp_context; /* one HIP device + stream + scratch */
+
+int lp_abi_version(void);
+int lp_device_count(void);
+/* Binds HIP device `device` (must be gfx950-class; fails loudly otherwise).
+ * `stream` may be NULL (the library creates its own non-blocking stream) or an
+ * existing hipStream_t owned by the caller.                                      */
+int lp_context_create(int device, void* stream, lp_context** ctx_out);
+void lp_context_destroy(lp_context* ctx);
+const char* lp_last_error(const lp_context* ctx);
+const char* lp_status_string(int status);
+int lp_context_sync(lp_context* ctx);
+
+/* =========================================================================
+ * Simplex  —  replaces Solver::solveWithBasis / simplexIter / computeBFS
+ *             (SimplexSolover.h:408-451, :135-209, :117-133)
+ * ========================================================================= */
+
+/* One-shot: upload, solve on the GPU, download.
+ * basis_in : Canonical::GetBasisIndices() (m entries, by basis position).
+ * eps      : Solver::EPS (1e-9, SimplexSolover.h:13).
+ * max_iter : MAX_ITER (10000, SimplexSolover.h:426).
+ * x_out    : n_orig doubles = solve()'s return value (:435-439).
+ * basis_out: m ints, final basis BY POSITION (the reference's local N, :419).
+ * obj_out  : c . x (Canonical::Evaluate, Canonical.cpp:86).
+ * iters_out: pivots executed.   Any of basis_out/obj_out/iters_out may be NULL. */
+int lp_simplex_solve(lp_context* ctx, const double* A, int m, int n, const double* b,
+                     const double* c, const int* basis_in, int maximize, int n_orig, double eps,
+                     int max_iter, double* x_out, int* basis_out, double* obj_out, int* iters_out);
+
+/* Device-resident form (used by bench.py so that timed regions start with the
+ * tableau already in HBM).                                                       */
+typedef struct lp_simplex_problem lp_simplex_problem;
+
+enum {
+    LP_SIMPLEX_ALGO_AUTO = 0,
+    LP_SIMPLEX_ALGO_LAUNCH = 1,    /* one select + one rank-1-update launch per pivot   */
+    LP_SIMPLEX_ALGO_PERSISTENT = 2 /* whole solve in one cooperative persistent launch  */
+};
+
+typedef struct lp_simplex_stats {
+    int status;
+    int pivots;             /* pivots executed                                            */
+    int launches;           /* kernel launches issued                                      */
+    float solve_ms;         /* HIP-event time of the whole solve on the library's stream  */
+    float update_ms;        /* HIP-event time spent in rank-1 update launches (0 if not
+                               separately measurable for the chosen algorithm)            */
+    int update_launches;    /* launches counted in update_ms                               */
+    double bytes_per_pivot; /* algorithmic bytes of one rank-1 update: 16*m*(n+1)          */
+} lp_simplex_stats;
+
+int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
+                      const double* c, const int* basis_in, int maximize, int n_orig,
+                      lp_simplex_problem** problem_out);
+/* Restores the initial tableau (device-to-device) so a solve can be repeated.   */
+int lp_simplex_reset(lp_simplex_problem* p);
+int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
+                   lp_simplex_stats* stats_out);
+/* trace_*: first trace_cap pivots (entering column, leaving POSITION); tableau_out:
+ * (m+1) x (n+1) row-major, rows by basis position, row m = reduced costs,
+ * column n = xB.  Every pointer may be NULL.                                      */
+int lp_simplex_download(lp_simplex_problem* p, double* x_out, int* basis_out, double* obj_out,
+                        int* trace_enter, int* trace_leave, int trace_cap, double* tableau_out);
+void lp_simplex_free(lp_simplex_problem* p);
+
+/* Times `iters` launches of the rank-1 update kernel alone on the problem's
+ * current tableau (pivot element (row, col) must be non-zero; the tableau is
+ * restored afterwards).  ms_per_launch = HIP-event time / iters.                  */
+int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,
+                          float* ms_per_launch_out);
+
+/* Batched simplex (BASELINE.json configs[4]): `batch` independent LPs of one
+ * shape, one LP per workgroup.  Arrays are concatenated per LP: A batch*m*n
+ * (each column-major), b batch*m, c batch*n, basis_in batch*m; outputs x_out
+ * batch*n_orig, basis_out batch*m, obj_out/iters_out/status_out batch.           */
+int lp_simplex_solve_batched(lp_context* ctx, int batch, const double* A, int m, int n,
+                             const double* b, const double* c, const int* basis_in, int maximize,
+                             int n_orig, double eps, int max_iter, double* x_out, int* basis_out,
+                             double* obj_out, int* iters_out, int* status_out);
+
+typedef struct lp_batched_problem lp_batched_problem;
+int lp_batched_upload(lp_context* ctx, int batch, const double* A, int m, int n, const double* b,
+                      const double* c, const int* basis_in, int maximize, int n_orig,
+                      lp_batched_problem** problem_out);
+int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_out);
+int lp_batched_download(lp_batched_problem* p, double* x_out, int* basis_out, double* obj_out,
+                        int* iters_out, int* status_out);
+void lp_batched_free(lp_batched_problem* p);
+
+/* =========================================================================
+ * Enumeration — EnumerationSolver (src/EnumerationSolver.h:3-10 is a stub; spec
+ * README.md:27,40-42; per-basis kernel = Canonical::GetBasicSolution /
+ * IsFeasibleBasis / Evaluate, Canonical.cpp:165-197, :79-87).
+ * Semantics: rank k in [0, C(n,m)) = k-th sorted
+ * m-subset in lexicographic order; per subset a Gauss-Jordan solve with partial
+ * pivoting; singular / infeasible (some xB < -1e-9) / feasible; winner = best
+ * objective, ties within 1e-9 broken towards the smallest rank.
+ * ========================================================================= */
+
+uint64_t lp_binom(int n, int k); /* C(n,k), 0 on overflow */
+
+/* One-shot single-GPU solve.  counts_out[3] = {feasible, infeasible, singular}. */
+int lp_enum_solve(lp_context* ctx, const double* A, int m, int n, const double* b,
+                  const double* c, int maximize, int n_orig, double* x_out, int* basis_out,
+                  uint64_t* rank_out, double* obj_out, uint64_t* counts_out);
+
+typedef struct lp_enum_problem lp_enum_problem;
+
+enum {
+    LP_ENUM_ALGO_AUTO = 0,
+    LP_ENUM_ALGO_DIRECT = 1, /* one independent m x m solve per subset                   */
+    LP_ENUM_ALGO_PREFIX = 2  /* shared-prefix elimination over the combination tree
+                                (bit-identical results, far fewer flops)                 */
+};
+
+typedef struct lp_enum_stats {
+    float kernel_ms;    /* HIP-event time of the enumeration kernel(s)                    */
+    uint64_t subsets;   /* subsets processed                                              */
+    int launches;
+} lp_enum_stats;
+
+int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
+                   const double* c, int maximize, lp_enum_problem** problem_out);
+/* Pass 1 over the shard [rank_begin, rank_end): best objective over feasible
+ * subsets (-inf/+inf if none) and the three counts.  This is what each GPU runs
+ * on its slice of the rank space; the caller then reduces zbest over GPUs
+ * (one RCCL all-reduce).                                                          */
+int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, int algo,
+                  double* zbest_out, uint64_t* counts_out, lp_enum_stats* stats_out);
+/* Pass 2: smallest feasible rank in [rank_begin, rank_end) whose objective is
+ * within tol of zstar on the better-or-equal side; UINT64_MAX if none.           */
+int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, double zstar,
+                         double tol, uint64_t* rank_out);
+/* Vertex of one rank: x (n_orig), sorted basis (m), objective, verdict.          */
+int lp_enum_vertex(lp_enum_problem* p, uint64_t rank, int n_orig, double* x_out, int* basis_out,
+                   double* obj_out, int* verdict_out);
+void lp_enum_free(lp_enum_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

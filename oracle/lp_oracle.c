@@ -681,7 +681,7 @@ int orc_next_subset(int n, int m, int* subset) {
  *                                      W[i][c] = fma(l, W[p][c], W[i][c])  for c > t
  *     row p:                           W[p][c] = W[p][c]*inv               for c > t
  *   singular iff min_t|piv_t| <= DBL_EPSILON * m * max_t|piv_t|
- *   x(S_t) = W[p_t][m];  feasible iff every x >= -1e-9
+ *   x(S_t) = W[p_t][m];  feasible iff every x >= -1e-9 (a NaN is infeasible)
  *   z = fma(c[S_t], x(S_t), z) for t ascending, from z = 0
  */
 int orc_enum_subset(const double* A, int m, int n, const double* b, const double* c,
@@ -730,7 +730,7 @@ int orc_enum_subset(const double* A, int m, int n, const double* b, const double
         for (int t = 0; t < m; ++t) {
             double xv = W[rowpos[t] * ld + m];
             if (xB_out) xB_out[t] = xv;
-            if (xv < -1e-9) status = ORC_SUBSET_INFEASIBLE; /* Canonical.cpp:171 */
+            if (!(xv >= -1e-9)) status = ORC_SUBSET_INFEASIBLE; /* Canonical.cpp:171; NaN counts as infeasible */
             z = fma(c[subset[t]], xv, z);
         }
         if (z_out) *z_out = z;

@@ -1,0 +1,81 @@
+"""Builds the in-tree native libraries (hipcc for gfx950, g++ for the host classes).
+
+The built files live under simplexmethod_amd/_build/ (git-ignored, but they travel
+to the GPU box with the repo snapshot).  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+HOST = os.path.join(_HERE, "host")
+OUT = os.path.join(_HERE, "_build")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+HIP_LIB = os.path.join(OUT, "libsimplexmethod_hip.so")
+HOST_LIB = os.path.join(OUT, "libsimplexmethod_host.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP hot path cannot be built")
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = _sources(CSRC, (".hip",))
+    deps = srcs + _sources(CSRC, (".hpp",)) + _sources(INCLUDE, (".h",))
+    if not force and _newer(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", HIP_LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    """C++ mirror of the reference's problem classes + Solver/EnumerationSolver wrappers."""
+    os.makedirs(OUT, exist_ok=True)
+    if not os.path.isdir(HOST):
+        return None
+    srcs = _sources(HOST, (".cpp",))
+    if not srcs:
+        return None
+    deps = srcs + _sources(HOST, (".h",)) + _sources(INCLUDE, (".h",))
+    if not force and _newer(HOST_LIB, deps):
+        return HOST_LIB
+    build_hip(force=False, verbose=verbose)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-I", INCLUDE,
+           "-I", HOST, "-o", HOST_LIB] + srcs + ["-L", OUT, "-lsimplexmethod_hip",
+                                                  "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_all(force="--force" in sys.argv, verbose=True))

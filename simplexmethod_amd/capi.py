@@ -1,0 +1,395 @@
+"""ctypes binding of include/simplexmethod_amd.h (libsimplexmethod_hip.so).
+
+There is no CPU fallback here or in the library: `load()` raises if the shared
+object is missing, and `Context()` raises if no gfx950 device is usable.
+Matrices are passed as (m, n) numpy arrays and converted to the ABI's column-major
+layout (Eigen's default, /root/reference/src/ProblemTypes/Canonical.cpp:10).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OPTIMAL, UNBOUNDED, ITER_LIMIT, SINGULAR, INFEASIBLE, BAD_ARG = range(6)
+SUBSET_FEASIBLE, SUBSET_INFEASIBLE, SUBSET_SINGULAR = range(3)
+SIMPLEX_AUTO, SIMPLEX_LAUNCH, SIMPLEX_PERSISTENT = 0, 1, 2
+ENUM_AUTO, ENUM_DIRECT, ENUM_PREFIX = 0, 1, 2
+U64_MAX = (1 << 64) - 1
+EPS = 1e-9        # Solver::EPS, SimplexSolover.h:13
+MAX_ITER = 10000  # SimplexSolover.h:426
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_u64p = C.POINTER(C.c_uint64)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class SimplexStats(C.Structure):
+    _fields_ = [("status", C.c_int), ("pivots", C.c_int), ("launches", C.c_int),
+                ("solve_ms", C.c_float), ("update_ms", C.c_float), ("update_launches", C.c_int),
+                ("bytes_per_pivot", C.c_double)]
+
+
+class EnumStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("subsets", C.c_uint64), ("launches", C.c_int)]
+
+
+# name -> (restype, argtypes); also the list tests check against the header's declarations
+SIGNATURES = {
+    "lp_abi_version": (C.c_int, []),
+    "lp_device_count": (C.c_int, []),
+    "lp_context_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "lp_context_destroy": (None, [_vp]),
+    "lp_last_error": (C.c_char_p, [_vp]),
+    "lp_status_string": (C.c_char_p, [C.c_int]),
+    "lp_context_sync": (C.c_int, [_vp]),
+    "lp_simplex_solve": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _ip, C.c_int, C.c_int,
+                                   C.c_double, C.c_int, _dp, _ip, _dp, _ip]),
+    "lp_simplex_upload": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, _ip, C.c_int, C.c_int,
+                                    C.POINTER(_vp)]),
+    "lp_simplex_reset": (C.c_int, [_vp]),
+    "lp_simplex_run": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.POINTER(SimplexStats)]),
+    "lp_simplex_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, C.c_int, _dp]),
+    "lp_simplex_free": (None, [_vp]),
+    "lp_bench_rank1_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp]),
+    "lp_simplex_solve_batched": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _ip,
+                                           C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
+                                           _ip, _ip]),
+    "lp_batched_upload": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _ip, C.c_int,
+                                    C.c_int, C.POINTER(_vp)]),
+    "lp_batched_run": (C.c_int, [_vp, C.c_double, C.c_int, _fp]),
+    "lp_batched_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip]),
+    "lp_batched_free": (None, [_vp]),
+    "lp_binom": (C.c_uint64, [C.c_int, C.c_int]),
+    "lp_enum_solve": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _ip,
+                                _u64p, _dp, _u64p]),
+    "lp_enum_upload": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.POINTER(_vp)]),
+    "lp_enum_range": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_int, _dp, _u64p,
+                                C.POINTER(EnumStats)]),
+    "lp_enum_first_within": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _u64p]),
+    "lp_enum_vertex": (C.c_int, [_vp, C.c_uint64, C.c_int, _dp, _ip, _dp, _ip]),
+    "lp_enum_free": (None, [_vp]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.HIP_LIB
+
+
+def load():
+    """Loads the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError = ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class LPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"status {code}: {msg}")
+        self.code = code
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def colmajor(A):
+    A = np.asarray(A, dtype=np.float64)
+    return np.ascontiguousarray(A.T).reshape(-1)
+
+
+# ---- synthetic LPs; bit-identical to oracle/lp_oracle.c:orc_gen_lp ----
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _u01(key, count, start=0):
+    with np.errstate(over="ignore"):
+        k = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = _mix64(np.uint64(key) + k * np.uint64(0x9E3779B97F4A7C15))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def gen_lp(seed, m, n):
+    """Dense random canonical LP [A_orig | I]: A_orig ~ U(0,1), b ~ U(1,2)*(n-m)/2, c ~ U(0,1)
+    on the original columns, slack basis, maximise.  Returns (A (m,n), b, c, basis)."""
+    no = n - m
+    with np.errstate(over="ignore"):
+        key = int(_mix64(np.uint64(seed) + np.uint64(0x5851F42D4C957F2D)))
+    u = _u01(key, no * m + m + no)
+    A = np.zeros((m, n))
+    A[:, :no] = u[:no * m].reshape(no, m).T
+    A[:, no:] = np.eye(m)
+    b = (1.0 + u[no * m:no * m + m]) * (no * 0.5)
+    c = np.zeros(n)
+    c[:no] = u[no * m + m:]
+    basis = np.arange(no, n, dtype=np.int32)
+    return A, b, c, basis
+
+
+class Context:
+    """One HIP device + stream (lp_context)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.lp_context_create(device, stream, C.byref(h))
+        if rc != 0:
+            raise LPError(rc, "lp_context_create failed: " +
+                          (self.lib.lp_last_error(None) or b"").decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lp_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return (self.lib.lp_last_error(self.h) or b"").decode()
+
+    def check(self, rc):
+        if rc < 0 or rc == BAD_ARG:
+            raise LPError(rc, self.error() or self.lib.lp_status_string(rc).decode())
+        return rc
+
+    # ---- simplex -------------------------------------------------------------------------
+    def simplex_solve(self, A, b, c, basis, maximize=True, n_orig=None, eps=EPS,
+                      max_iter=MAX_ITER):
+        A = np.asarray(A, dtype=np.float64)
+        m, n = A.shape
+        n_orig = n if n_orig is None else n_orig
+        Af, b, c = colmajor(A), _f64(b), _f64(c)
+        basis = np.ascontiguousarray(basis, dtype=np.int32)
+        x = np.zeros(max(n_orig, 1))
+        bo = np.zeros(m, dtype=np.int32)
+        obj = C.c_double(float("nan"))
+        it = C.c_int(0)
+        rc = self.check(self.lib.lp_simplex_solve(self.h, _d(Af), m, n, _d(b), _d(c), _i(basis),
+                                                  int(maximize), n_orig, eps, max_iter, _d(x),
+                                                  _i(bo), C.byref(obj), C.byref(it)))
+        return dict(status=rc, x=x[:n_orig], basis=bo, obj=obj.value, iters=it.value)
+
+    def simplex_problem(self, A, b, c, basis, maximize=True, n_orig=None):
+        return SimplexProblem(self, A, b, c, basis, maximize, n_orig)
+
+    def simplex_solve_batched(self, A, b, c, basis, maximize=True, n_orig=None, eps=EPS,
+                              max_iter=MAX_ITER):
+        """A: (batch, m, n); b: (batch, m); c: (batch, n); basis: (batch, m)."""
+        A = np.asarray(A, dtype=np.float64)
+        batch, m, n = A.shape
+        n_orig = n if n_orig is None else n_orig
+        Af = np.ascontiguousarray(np.transpose(A, (0, 2, 1))).reshape(-1)
+        b, c = _f64(b).reshape(-1), _f64(c).reshape(-1)
+        basis = np.ascontiguousarray(basis, dtype=np.int32).reshape(-1)
+        x = np.zeros((batch, n_orig))
+        bo = np.zeros((batch, m), dtype=np.int32)
+        obj = np.full(batch, np.nan)
+        it = np.zeros(batch, dtype=np.int32)
+        st = np.zeros(batch, dtype=np.int32)
+        self.check(self.lib.lp_simplex_solve_batched(self.h, batch, _d(Af), m, n, _d(b), _d(c),
+                                                     _i(basis), int(maximize), n_orig, eps,
+                                                     max_iter, _d(x), _i(bo), _d(obj), _i(it),
+                                                     _i(st)))
+        return dict(status=st, x=x, basis=bo, obj=obj, iters=it)
+
+    def batched_problem(self, A, b, c, basis, maximize=True, n_orig=None):
+        return BatchedProblem(self, A, b, c, basis, maximize, n_orig)
+
+    # ---- enumeration ---------------------------------------------------------------------
+    def enum_solve(self, A, b, c, maximize=True, n_orig=None):
+        A = np.asarray(A, dtype=np.float64)
+        m, n = A.shape
+        n_orig = n if n_orig is None else n_orig
+        Af, b, c = colmajor(A), _f64(b), _f64(c)
+        x = np.zeros(n_orig)
+        bo = np.zeros(m, dtype=np.int32)
+        rank = C.c_uint64(0)
+        obj = C.c_double(float("nan"))
+        counts = (C.c_uint64 * 3)()
+        rc = self.check(self.lib.lp_enum_solve(self.h, _d(Af), m, n, _d(b), _d(c), int(maximize),
+                                               n_orig, _d(x), _i(bo), C.byref(rank), C.byref(obj),
+                                               counts))
+        return dict(status=rc, x=x, basis=bo, rank=int(rank.value), obj=obj.value,
+                    counts=[int(v) for v in counts])
+
+    def enum_problem(self, A, b, c, maximize=True):
+        return EnumProblem(self, A, b, c, maximize)
+
+
+class SimplexProblem:
+    """Device-resident tableau (lp_simplex_problem)."""
+
+    def __init__(self, ctx, A, b, c, basis, maximize=True, n_orig=None):
+        A = np.asarray(A, dtype=np.float64)
+        self.ctx, self.m, self.n = ctx, A.shape[0], A.shape[1]
+        self.n_orig = self.n if n_orig is None else n_orig
+        Af, b, c = colmajor(A), _f64(b), _f64(c)
+        basis = np.ascontiguousarray(basis, dtype=np.int32)
+        h = _vp()
+        ctx.check(ctx.lib.lp_simplex_upload(ctx.h, _d(Af), self.m, self.n, _d(b), _d(c), _i(basis),
+                                            int(maximize), self.n_orig, C.byref(h)))
+        self.h = h
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.lp_simplex_reset(self.h))
+
+    def run(self, eps=EPS, max_iter=MAX_ITER, algo=SIMPLEX_AUTO):
+        st = SimplexStats()
+        rc = self.ctx.check(self.ctx.lib.lp_simplex_run(self.h, eps, max_iter, algo, C.byref(st)))
+        return rc, st
+
+    def download(self, trace_cap=0, want_tableau=False):
+        x = np.zeros(self.n_orig)
+        bo = np.zeros(self.m, dtype=np.int32)
+        obj = C.c_double(float("nan"))
+        te = np.full(max(trace_cap, 1), -1, dtype=np.int32)
+        tl = np.full(max(trace_cap, 1), -1, dtype=np.int32)
+        tab = np.zeros((self.m + 1, self.n + 1)) if want_tableau else None
+        self.ctx.check(self.ctx.lib.lp_simplex_download(self.h, _d(x), _i(bo), C.byref(obj), _i(te),
+                                                        _i(tl), trace_cap, _d(tab)))
+        return dict(x=x, basis=bo, obj=obj.value, trace_enter=te[:trace_cap],
+                    trace_leave=tl[:trace_cap], tableau=tab)
+
+    def bench_update(self, row, col, iters):
+        ms = C.c_float(0.0)
+        self.ctx.check(self.ctx.lib.lp_bench_rank1_update(self.h, row, col, iters, C.byref(ms)))
+        return ms.value
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.lp_simplex_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class BatchedProblem:
+    def __init__(self, ctx, A, b, c, basis, maximize=True, n_orig=None):
+        A = np.asarray(A, dtype=np.float64)
+        self.ctx = ctx
+        self.batch, self.m, self.n = A.shape
+        self.n_orig = self.n if n_orig is None else n_orig
+        Af = np.ascontiguousarray(np.transpose(A, (0, 2, 1))).reshape(-1)
+        b, c = _f64(b).reshape(-1), _f64(c).reshape(-1)
+        basis = np.ascontiguousarray(basis, dtype=np.int32).reshape(-1)
+        h = _vp()
+        ctx.check(ctx.lib.lp_batched_upload(ctx.h, self.batch, _d(Af), self.m, self.n, _d(b), _d(c),
+                                            _i(basis), int(maximize), self.n_orig, C.byref(h)))
+        self.h = h
+
+    def run(self, eps=EPS, max_iter=MAX_ITER):
+        ms = C.c_float(0.0)
+        self.ctx.check(self.ctx.lib.lp_batched_run(self.h, eps, max_iter, C.byref(ms)))
+        return ms.value
+
+    def download(self):
+        x = np.zeros((self.batch, self.n_orig))
+        bo = np.zeros((self.batch, self.m), dtype=np.int32)
+        obj = np.full(self.batch, np.nan)
+        it = np.zeros(self.batch, dtype=np.int32)
+        st = np.zeros(self.batch, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.lp_batched_download(self.h, _d(x), _i(bo), _d(obj), _i(it),
+                                                        _i(st)))
+        return dict(status=st, x=x, basis=bo, obj=obj, iters=it)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.lp_batched_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class EnumProblem:
+    """Device-resident enumeration problem (lp_enum_problem)."""
+
+    def __init__(self, ctx, A, b, c, maximize=True):
+        A = np.asarray(A, dtype=np.float64)
+        self.ctx, self.m, self.n = ctx, A.shape[0], A.shape[1]
+        self.maximize = bool(maximize)
+        Af, b, c = colmajor(A), _f64(b), _f64(c)
+        h = _vp()
+        ctx.check(ctx.lib.lp_enum_upload(ctx.h, _d(Af), self.m, self.n, _d(b), _d(c),
+                                         int(maximize), C.byref(h)))
+        self.h = h
+        self.total = int(ctx.lib.lp_binom(self.n, self.m))
+
+    def range(self, begin, end, algo=ENUM_AUTO):
+        z = C.c_double(0.0)
+        counts = (C.c_uint64 * 3)()
+        st = EnumStats()
+        rc = self.ctx.check(self.ctx.lib.lp_enum_range(self.h, begin, end, algo, C.byref(z), counts,
+                                                       C.byref(st)))
+        return rc, z.value, [int(v) for v in counts], st
+
+    def first_within(self, begin, end, zstar, tol=1e-9):
+        r = C.c_uint64(0)
+        self.ctx.check(self.ctx.lib.lp_enum_first_within(self.h, begin, end, zstar, tol,
+                                                         C.byref(r)))
+        return int(r.value)
+
+    def vertex(self, rank, n_orig=None):
+        n_orig = self.n if n_orig is None else n_orig
+        x = np.zeros(n_orig)
+        bo = np.zeros(self.m, dtype=np.int32)
+        obj = C.c_double(float("nan"))
+        verdict = C.c_int(-1)
+        self.ctx.check(self.ctx.lib.lp_enum_vertex(self.h, rank, n_orig, _d(x), _i(bo),
+                                                   C.byref(obj), C.byref(verdict)))
+        return dict(x=x, basis=bo, obj=obj.value, verdict=verdict.value)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.lp_enum_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,588 @@
+// capi.hip — the extern "C" boundary (include/simplexmethod_amd.h): argument checks that
+// mirror the reference's constructors, uploads/downloads, and dispatch to the kernels.
+#include <cmath>
+
+#include "enum_problem.hpp"
+#include "lp_internal.hpp"
+#include "simplex_problem.hpp"
+
+uint64_t lp_host_binom(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    if (k > n - k) k = n - k;
+    unsigned __int128 r = 1;
+    for (int i = 1; i <= k; ++i) {
+        r = r * (unsigned)(n - k + i) / (unsigned)i;
+        if (r > (unsigned __int128)UINT64_MAX) return 0;
+    }
+    return (uint64_t)r;
+}
+
+extern "C" {
+
+int lp_abi_version(void) { return LP_ABI_VERSION; }
+
+int lp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* lp_status_string(int status) {
+    switch (status) {
+        case LP_OPTIMAL: return "optimal";
+        case LP_UNBOUNDED: return "objective unbounded";
+        case LP_ITER_LIMIT: return "iteration limit reached";
+        case LP_SINGULAR: return "singular basis matrix";
+        case LP_INFEASIBLE: return "no feasible basis";
+        case LP_BAD_ARG: return "bad argument";
+        default: return status < 0 ? "HIP runtime error" : "unknown status";
+    }
+}
+
+static thread_local std::string g_create_error;
+
+int lp_context_create(int device, void* stream, lp_context** ctx_out) {
+    if (!ctx_out) return LP_BAD_ARG;
+    *ctx_out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = "no HIP device visible (this library has no CPU fallback)";
+        return e != hipSuccess ? -(int)e : -(int)hipErrorNoDevice;
+    }
+    if (device < 0 || device >= count) return LP_BAD_ARG;
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return -(int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return -(int)e;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName +
+                         ", kernels are built for gfx950 only";
+        return -(int)hipErrorNoBinaryForGpu;
+    }
+    lp_context* ctx = new lp_context();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return -(int)e;
+        }
+        ctx->owns_stream = true;
+    }
+    *ctx_out = ctx;
+    return LP_OPTIMAL;
+}
+
+void lp_context_destroy(lp_context* ctx) {
+    if (!ctx) return;
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* lp_last_error(const lp_context* ctx) {
+    return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+int lp_context_sync(lp_context* ctx) {
+    if (!ctx) return LP_BAD_ARG;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LP_OPTIMAL;
+}
+
+// ===========================================================================
+// simplex
+// ===========================================================================
+
+// Canonical's constructor checks (Canonical.cpp:27-46) + SetOriginalVariablesCount (:156-163).
+static int check_canonical(lp_context* ctx, const double* A, int m, int n, const double* b,
+                           const double* c, const int* basis, int n_orig) {
+    if (!A || !b || !c || !basis) LP_FAIL(ctx, LP_BAD_ARG, "null problem array");
+    if (m <= 0 || n <= 0) LP_FAIL(ctx, LP_BAD_ARG, "empty problem");
+    if (n < m) LP_FAIL(ctx, LP_BAD_ARG, "fewer columns than rows");
+    if (n_orig <= 0 || n_orig > n) LP_FAIL(ctx, LP_BAD_ARG, "bad original variable count");
+    for (int t = 0; t < m; ++t)
+        if (basis[t] < 0 || basis[t] >= n) LP_FAIL(ctx, LP_BAD_ARG, "basis index out of range");
+    return LP_OPTIMAL;
+}
+
+void lp_simplex_free(lp_simplex_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    SimplexDev& d = p->dev;
+    (void)hipFree(d.T); (void)hipFree(d.lcol); (void)hipFree(d.prow); (void)hipFree(d.basis);
+    (void)hipFree(d.nonbasic); (void)hipFree(d.rowused); (void)hipFree(d.rowpos);
+    (void)hipFree(d.trace_enter); (void)hipFree(d.trace_leave); (void)hipFree(d.state);
+    (void)hipFree(p->dT0); (void)hipFree(p->dscratchT); (void)hipFree(p->dbasis0);
+    (void)hipFree(p->dnonbasic0); (void)hipFree(p->dx);
+    if (p->h_state) (void)hipHostFree(p->h_state);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
+                      const double* c, const int* basis_in, int maximize, int n_orig,
+                      lp_simplex_problem** problem_out) {
+    if (!ctx || !problem_out) return LP_BAD_ARG;
+    *problem_out = nullptr;
+    int rc = check_canonical(ctx, A, m, n, b, c, basis_in, n_orig);
+    if (rc) return rc;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    lp_simplex_problem* p = new lp_simplex_problem();
+    p->ctx = ctx;
+    p->n_orig = n_orig;
+    p->h_c.assign(c, c + n);
+    SimplexDev& d = p->dev;
+    d.m = m;
+    d.n = n;
+    d.ld = ((n + 1 + 7) / 8) * 8;
+    d.maximize = maximize ? 1 : 0;
+    d.trace_cap = 16384;
+    const size_t rows = (size_t)m + 1;
+    p->tableau_bytes = sizeof(double) * rows * (size_t)d.ld;
+#define LP_TRY(expr)                        \
+    do {                                    \
+        hipError_t _e = (expr);             \
+        if (_e != hipSuccess) {             \
+            ctx->last_error = #expr;        \
+            lp_simplex_free(p);             \
+            return -(int)_e;                \
+        }                                   \
+    } while (0)
+    LP_TRY(hipMalloc(&d.T, p->tableau_bytes));
+    LP_TRY(hipMalloc(&p->dT0, p->tableau_bytes));
+    LP_TRY(hipMalloc(&p->dscratchT, p->tableau_bytes));
+    LP_TRY(hipMalloc(&d.lcol, sizeof(double) * rows));
+    LP_TRY(hipMalloc(&d.prow, sizeof(double) * (size_t)d.ld));
+    LP_TRY(hipMalloc(&d.basis, sizeof(int) * (size_t)m));
+    LP_TRY(hipMalloc(&p->dbasis0, sizeof(int) * (size_t)m));
+    LP_TRY(hipMalloc(&d.nonbasic, (size_t)n));
+    LP_TRY(hipMalloc(&p->dnonbasic0, (size_t)n));
+    LP_TRY(hipMalloc(&d.rowused, (size_t)m));
+    LP_TRY(hipMalloc(&d.rowpos, sizeof(int) * (size_t)m));
+    LP_TRY(hipMalloc(&d.trace_enter, sizeof(int) * (size_t)d.trace_cap));
+    LP_TRY(hipMalloc(&d.trace_leave, sizeof(int) * (size_t)d.trace_cap));
+    LP_TRY(hipMalloc(&d.state, sizeof(SimplexState)));
+    LP_TRY(hipMalloc(&p->dx, sizeof(double) * (size_t)n));
+    LP_TRY(hipHostMalloc(&p->h_state, sizeof(SimplexState)));
+    LP_TRY(hipEventCreate(&p->ev0));
+    LP_TRY(hipEventCreate(&p->ev1));
+
+    // Initial tableau [A | b] with the cost row c underneath, row-major (host-side O(mn)
+    // layout change: Eigen's column-major A -> rows that the update kernel streams).
+    std::vector<double> T(rows * (size_t)d.ld, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < m; ++i) T[(size_t)i * d.ld + j] = A[(size_t)j * m + i];
+    for (int i = 0; i < m; ++i) T[(size_t)i * d.ld + n] = b[i];
+    for (int j = 0; j < n; ++j) T[(size_t)m * d.ld + j] = c[j];
+    std::vector<unsigned char> nonbasic((size_t)n, 1);
+    for (int t = 0; t < m; ++t) nonbasic[(size_t)basis_in[t]] = 0;
+    hipStream_t s = ctx->stream;
+    LP_TRY(hipMemcpyAsync(d.T, T.data(), p->tableau_bytes, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(d.basis, basis_in, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dbasis0, basis_in, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(d.nonbasic, nonbasic.data(), (size_t)n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dnonbasic0, nonbasic.data(), (size_t)n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipStreamSynchronize(s));
+#undef LP_TRY
+
+    // computeBFS (SimplexSolover.h:423): nothing to do for the slack identity basis with
+    // zero basic costs (Symmetrical::ToCanonical, Symmetrical.cpp:169-188); otherwise m
+    // Gauss-Jordan pivots on the device.
+    bool identity = true;
+    for (int t = 0; t < m && identity; ++t) {
+        if (c[basis_in[t]] != 0.0) identity = false;
+        for (int i = 0; i < m && identity; ++i)
+            if (A[(size_t)basis_in[t] * m + i] != ((i == t) ? 1.0 : 0.0)) identity = false;
+    }
+    p->init_status = LP_OPTIMAL;
+    if (!identity) {
+        rc = lp_simplex_crash(p);
+        if (rc < 0) {
+            lp_simplex_free(p);
+            return rc;
+        }
+        p->init_status = rc;
+    }
+    hipError_t e = hipMemcpyAsync(p->dT0, d.T, p->tableau_bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        lp_simplex_free(p);
+        return -(int)e;
+    }
+    *problem_out = p;
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_reset(lp_simplex_problem* p) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    const SimplexDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    LP_HIP(ctx, hipMemcpyAsync(d.T, p->dT0, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipMemcpyAsync(d.basis, p->dbasis0, sizeof(int) * (size_t)d.m, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipMemcpyAsync(d.nonbasic, p->dnonbasic0, (size_t)d.n, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    p->last_status = -100;
+    p->last_iters = 0;
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
+                   lp_simplex_stats* stats_out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out));
+    if (p->init_status != LP_OPTIMAL) {  // "Singular basis matrix", SimplexSolover.h:125-126
+        if (stats_out) stats_out->status = p->init_status;
+        p->last_status = p->init_status;
+        return p->init_status;
+    }
+    switch (algo) {
+        case LP_SIMPLEX_ALGO_AUTO:
+        case LP_SIMPLEX_ALGO_LAUNCH:
+            return lp_simplex_run_launch(p, eps, max_iter, stats_out);
+        default:
+            LP_FAIL(ctx, LP_BAD_ARG, "unknown simplex algorithm id");
+    }
+}
+
+int lp_simplex_download(lp_simplex_problem* p, double* x_out, int* basis_out, double* obj_out,
+                        int* trace_enter, int* trace_leave, int trace_cap, double* tableau_out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    const SimplexDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    std::vector<double> x((size_t)d.n, 0.0);
+    if (x_out || obj_out) {
+        lp_simplex_extract_x(p, p->dx);
+        LP_HIP(ctx, hipMemcpyAsync(x.data(), p->dx, sizeof(double) * (size_t)d.n, hipMemcpyDeviceToHost, s));
+    }
+    if (basis_out)
+        LP_HIP(ctx, hipMemcpyAsync(basis_out, d.basis, sizeof(int) * (size_t)d.m, hipMemcpyDeviceToHost, s));
+    const int k = std::min(trace_cap, std::min(p->last_iters, d.trace_cap));
+    if (trace_enter && k > 0)
+        LP_HIP(ctx, hipMemcpyAsync(trace_enter, d.trace_enter, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost, s));
+    if (trace_leave && k > 0)
+        LP_HIP(ctx, hipMemcpyAsync(trace_leave, d.trace_leave, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost, s));
+    std::vector<double> T;
+    if (tableau_out) {
+        T.resize(((size_t)d.m + 1) * (size_t)d.ld);
+        LP_HIP(ctx, hipMemcpyAsync(T.data(), d.T, p->tableau_bytes, hipMemcpyDeviceToHost, s));
+    }
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    LP_HIP(ctx, hipGetLastError());
+    if (x_out)  // x.head(n_orig), SimplexSolover.h:435-438
+        for (int j = 0; j < p->n_orig; ++j) x_out[j] = x[(size_t)j];
+    if (obj_out) {  // Canonical::Evaluate, Canonical.cpp:86
+        double z = 0.0;
+        for (int j = 0; j < d.n; ++j) z += p->h_c[(size_t)j] * x[(size_t)j];
+        *obj_out = z;
+    }
+    if (tableau_out)
+        for (int i = 0; i <= d.m; ++i)
+            std::memcpy(tableau_out + (size_t)i * (d.n + 1), T.data() + (size_t)i * d.ld,
+                        sizeof(double) * (size_t)(d.n + 1));
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_solve(lp_context* ctx, const double* A, int m, int n, const double* b,
+                     const double* c, const int* basis_in, int maximize, int n_orig, double eps,
+                     int max_iter, double* x_out, int* basis_out, double* obj_out, int* iters_out) {
+    if (!ctx) return LP_BAD_ARG;
+    if (!x_out) LP_FAIL(ctx, LP_BAD_ARG, "x_out is null");
+    lp_simplex_problem* p = nullptr;
+    int rc = lp_simplex_upload(ctx, A, m, n, b, c, basis_in, maximize, n_orig, &p);
+    if (rc) return rc;
+    lp_simplex_stats st;
+    rc = lp_simplex_run(p, eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
+    if (iters_out) *iters_out = st.pivots;
+    if (rc == LP_OPTIMAL) {
+        rc = lp_simplex_download(p, x_out, basis_out, obj_out, nullptr, nullptr, 0, nullptr);
+    } else if (rc > 0 && basis_out) {
+        (void)lp_simplex_download(p, nullptr, basis_out, nullptr, nullptr, nullptr, 0, nullptr);
+    }
+    lp_simplex_free(p);
+    return rc;
+}
+
+int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,
+                          float* ms_per_launch_out) {
+    if (!p) return LP_BAD_ARG;
+    LP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    return lp_simplex_bench_update(p, row, col, iters, ms_per_launch_out);
+}
+
+// ===========================================================================
+// enumeration
+// ===========================================================================
+
+uint64_t lp_binom(int n, int k) { return lp_host_binom(n, k); }
+
+void lp_enum_free(lp_enum_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dbinom);
+    (void)hipFree(p->dev.result); (void)hipFree(p->dev.chunk_best);
+    (void)hipFree(p->dvx); (void)hipFree(p->dvi);
+    if (p->h_result) (void)hipHostFree(p->h_result);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
+                   const double* c, int maximize, lp_enum_problem** problem_out) {
+    if (!ctx || !problem_out) return LP_BAD_ARG;
+    *problem_out = nullptr;
+    if (!A || !b || !c) LP_FAIL(ctx, LP_BAD_ARG, "null problem array");
+    if (m <= 0 || n < m) LP_FAIL(ctx, LP_BAD_ARG, "need 0 < m <= n");
+    if (n > kEnumMaxN || m > kEnumMaxM)
+        LP_FAIL(ctx, LP_BAD_ARG, "enumeration supports n <= 64 and m <= 32 (ranks must fit 64 bits)");
+    if (lp_host_binom(n, m) == 0) LP_FAIL(ctx, LP_BAD_ARG, "C(n,m) overflows 64 bits");
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    lp_enum_problem* p = new lp_enum_problem();
+    p->ctx = ctx;
+    EnumDev& d = p->dev;
+    d.m = m;
+    d.n = n;
+    d.lda = n + 1;
+    d.maximize = maximize ? 1 : 0;
+    p->chunk_cap = 1 << 17;
+    std::vector<double> Arow((size_t)m * d.lda, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < m; ++i) Arow[(size_t)i * d.lda + j] = A[(size_t)j * m + i];
+    std::vector<unsigned long long> binom((size_t)(kEnumMaxN + 1) * kBinomK, 0ULL);
+    for (int i = 0; i <= kEnumMaxN; ++i)
+        for (int k = 0; k < kBinomK; ++k) binom[(size_t)i * kBinomK + k] = lp_host_binom(i, k);
+#define LP_TRY(expr)                        \
+    do {                                    \
+        hipError_t _e = (expr);             \
+        if (_e != hipSuccess) {             \
+            ctx->last_error = #expr;        \
+            lp_enum_free(p);                \
+            return -(int)_e;                \
+        }                                   \
+    } while (0)
+    hipStream_t s = ctx->stream;
+    LP_TRY(hipMalloc(&p->dA, sizeof(double) * Arow.size()));
+    LP_TRY(hipMalloc(&p->db, sizeof(double) * (size_t)m));
+    LP_TRY(hipMalloc(&p->dc, sizeof(double) * (size_t)n));
+    LP_TRY(hipMalloc(&p->dbinom, sizeof(unsigned long long) * binom.size()));
+    LP_TRY(hipMalloc(&d.result, sizeof(EnumResult)));
+    LP_TRY(hipMalloc(&d.chunk_best, sizeof(double) * (size_t)(p->chunk_cap + 64)));
+    LP_TRY(hipMalloc(&p->dvx, sizeof(double) * (kEnumMaxM + 1)));
+    LP_TRY(hipMalloc(&p->dvi, sizeof(int) * (kEnumMaxM + 1)));
+    LP_TRY(hipHostMalloc(&p->h_result, sizeof(EnumResult)));
+    LP_TRY(hipEventCreate(&p->ev0));
+    LP_TRY(hipEventCreate(&p->ev1));
+    LP_TRY(hipMemcpyAsync(p->dA, Arow.data(), sizeof(double) * Arow.size(), hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->db, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
+                          hipMemcpyHostToDevice, s));
+    LP_TRY(hipStreamSynchronize(s));
+#undef LP_TRY
+    d.A = p->dA;
+    d.b = p->db;
+    d.c = p->dc;
+    d.binom = p->dbinom;
+    *problem_out = p;
+    return LP_OPTIMAL;
+}
+
+static int check_range(lp_enum_problem* p, uint64_t begin, uint64_t end) {
+    const uint64_t total = lp_host_binom(p->dev.n, p->dev.m);
+    if (begin > end || end > total) LP_FAIL(p->ctx, LP_BAD_ARG, "rank range outside [0, C(n,m)]");
+    return LP_OPTIMAL;
+}
+
+int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, int algo,
+                  double* zbest_out, uint64_t* counts_out, lp_enum_stats* stats_out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = check_range(p, rank_begin, rank_end);
+    if (rc) return rc;
+    double score = -INFINITY;
+    uint64_t counts[3] = {0, 0, 0};
+    switch (algo) {
+        case LP_ENUM_ALGO_AUTO:
+        case LP_ENUM_ALGO_DIRECT:
+            rc = lp_enum_direct_range(p, rank_begin, rank_end, &score, counts, stats_out);
+            break;
+        default:
+            LP_FAIL(ctx, LP_BAD_ARG, "unknown enumeration algorithm id");
+    }
+    if (rc) return rc;
+    if (zbest_out) *zbest_out = p->dev.maximize ? score : -score;
+    if (counts_out)
+        for (int k = 0; k < 3; ++k) counts_out[k] = counts[k];
+    return counts[0] ? LP_OPTIMAL : LP_INFEASIBLE;
+}
+
+int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, double zstar,
+                         double tol, uint64_t* rank_out) {
+    if (!p || !rank_out) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = check_range(p, rank_begin, rank_end);
+    if (rc) return rc;
+    const double star = p->dev.maximize ? zstar : -zstar;
+    return lp_enum_direct_first(p, rank_begin, rank_end, star, tol, rank_out);
+}
+
+int lp_enum_vertex(lp_enum_problem* p, uint64_t rank, int n_orig, double* x_out, int* basis_out,
+                   double* obj_out, int* verdict_out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    const EnumDev& d = p->dev;
+    if (rank >= lp_host_binom(d.n, d.m)) LP_FAIL(ctx, LP_BAD_ARG, "rank >= C(n,m)");
+    if (n_orig <= 0 || n_orig > d.n) LP_FAIL(ctx, LP_BAD_ARG, "bad original variable count");
+    double xB[kEnumMaxM], z;
+    int S[kEnumMaxM], verdict;
+    int rc = lp_enum_direct_vertex(p, rank, xB, S, &z, &verdict);
+    if (rc) return rc;
+    if (x_out) {
+        for (int j = 0; j < n_orig; ++j) x_out[j] = 0.0;
+        for (int t = 0; t < d.m; ++t)
+            if (S[t] < n_orig) x_out[S[t]] = xB[t];
+    }
+    if (basis_out)
+        for (int t = 0; t < d.m; ++t) basis_out[t] = S[t];
+    if (obj_out) *obj_out = z;
+    if (verdict_out) *verdict_out = verdict;
+    return LP_OPTIMAL;
+}
+
+int lp_enum_solve(lp_context* ctx, const double* A, int m, int n, const double* b,
+                  const double* c, int maximize, int n_orig, double* x_out, int* basis_out,
+                  uint64_t* rank_out, double* obj_out, uint64_t* counts_out) {
+    if (!ctx) return LP_BAD_ARG;
+    if (n_orig <= 0 || n_orig > n) LP_FAIL(ctx, LP_BAD_ARG, "bad original variable count");
+    lp_enum_problem* p = nullptr;
+    int rc = lp_enum_upload(ctx, A, m, n, b, c, maximize, &p);
+    if (rc) return rc;
+    const uint64_t total = lp_host_binom(n, m);
+    double zstar = 0.0;
+    rc = lp_enum_range(p, 0, total, LP_ENUM_ALGO_AUTO, &zstar, counts_out, nullptr);
+    if (rc == LP_OPTIMAL) {
+        uint64_t rank = UINT64_MAX;
+        rc = lp_enum_first_within(p, 0, total, zstar, 1e-9, &rank);
+        if (rc == LP_OPTIMAL && rank == UINT64_MAX) {
+            ctx->last_error = "pass 2 found no rank within tolerance of the pass-1 optimum";
+            rc = LP_INFEASIBLE;
+        }
+        if (rc == LP_OPTIMAL) {
+            int verdict = 0;
+            rc = lp_enum_vertex(p, rank, n_orig, x_out, basis_out, obj_out, &verdict);
+            if (rank_out) *rank_out = rank;
+        }
+    }
+    lp_enum_free(p);
+    return rc;
+}
+
+// ===========================================================================
+// batched simplex — first version: LPs solved one after another on the device
+// ===========================================================================
+
+struct lp_batched_problem {
+    lp_context* ctx = nullptr;
+    int batch = 0, m = 0, n = 0, n_orig = 0;
+    std::vector<lp_simplex_problem*> lps;
+    std::vector<int> status, iters;
+};
+
+void lp_batched_free(lp_batched_problem* p) {
+    if (!p) return;
+    for (auto* q : p->lps) lp_simplex_free(q);
+    delete p;
+}
+
+int lp_batched_upload(lp_context* ctx, int batch, const double* A, int m, int n, const double* b,
+                      const double* c, const int* basis_in, int maximize, int n_orig,
+                      lp_batched_problem** problem_out) {
+    if (!ctx || !problem_out) return LP_BAD_ARG;
+    *problem_out = nullptr;
+    if (batch <= 0) LP_FAIL(ctx, LP_BAD_ARG, "batch must be positive");
+    lp_batched_problem* p = new lp_batched_problem();
+    p->ctx = ctx;
+    p->batch = batch;
+    p->m = m;
+    p->n = n;
+    p->n_orig = n_orig;
+    p->status.assign((size_t)batch, -100);
+    p->iters.assign((size_t)batch, 0);
+    for (int k = 0; k < batch; ++k) {
+        lp_simplex_problem* q = nullptr;
+        int rc = lp_simplex_upload(ctx, A + (size_t)k * m * n, m, n, b + (size_t)k * m,
+                                   c + (size_t)k * n, basis_in + (size_t)k * m, maximize, n_orig, &q);
+        if (rc) {
+            lp_batched_free(p);
+            return rc;
+        }
+        p->lps.push_back(q);
+    }
+    *problem_out = p;
+    return LP_OPTIMAL;
+}
+
+int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_out) {
+    if (!p) return LP_BAD_ARG;
+    float total = 0.f;
+    for (int k = 0; k < p->batch; ++k) {
+        lp_simplex_stats st;
+        int rc = lp_simplex_reset(p->lps[(size_t)k]);
+        if (rc) return rc;
+        rc = lp_simplex_run(p->lps[(size_t)k], eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
+        if (rc < 0) return rc;
+        p->status[(size_t)k] = rc;
+        p->iters[(size_t)k] = st.pivots;
+        total += st.solve_ms;
+    }
+    if (ms_out) *ms_out = total;
+    return LP_OPTIMAL;
+}
+
+int lp_batched_download(lp_batched_problem* p, double* x_out, int* basis_out, double* obj_out,
+                        int* iters_out, int* status_out) {
+    if (!p) return LP_BAD_ARG;
+    for (int k = 0; k < p->batch; ++k) {
+        const bool ok = p->status[(size_t)k] == LP_OPTIMAL;
+        int rc = lp_simplex_download(p->lps[(size_t)k],
+                                     (x_out && ok) ? x_out + (size_t)k * p->n_orig : nullptr,
+                                     basis_out ? basis_out + (size_t)k * p->m : nullptr,
+                                     (obj_out && ok) ? obj_out + k : nullptr, nullptr, nullptr, 0,
+                                     nullptr);
+        if (rc) return rc;
+        if (iters_out) iters_out[k] = p->iters[(size_t)k];
+        if (status_out) status_out[k] = p->status[(size_t)k];
+    }
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_solve_batched(lp_context* ctx, int batch, const double* A, int m, int n,
+                             const double* b, const double* c, const int* basis_in, int maximize,
+                             int n_orig, double eps, int max_iter, double* x_out, int* basis_out,
+                             double* obj_out, int* iters_out, int* status_out) {
+    lp_batched_problem* p = nullptr;
+    int rc = lp_batched_upload(ctx, batch, A, m, n, b, c, basis_in, maximize, n_orig, &p);
+    if (rc) return rc;
+    rc = lp_batched_run(p, eps, max_iter, nullptr);
+    if (rc == LP_OPTIMAL) rc = lp_batched_download(p, x_out, basis_out, obj_out, iters_out, status_out);
+    lp_batched_free(p);
+    return rc;
+}
+
+}  // extern "C"

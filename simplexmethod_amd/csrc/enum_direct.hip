@@ -1,0 +1,386 @@
+// enum_direct.hip — vertex enumeration, one independent m x m solve per basis subset
+// (LP_ENUM_ALGO_DIRECT).
+//
+// EnumerationSolver is an empty stub in the reference (src/EnumerationSolver.h:3-10;
+// spec README.md:27,40-42); the per-basis step it needs is what
+// Canonical::GetBasicSolution / IsFeasibleBasis / Evaluate do for one basis
+// (src/ProblemTypes/Canonical.cpp:165-197, :79-87).  Semantics: SURVEY.md §8 row E1,
+// operation order: oracle/lp_oracle.c (orc_enum_subset) — replayed here bit for bit.
+//
+// Mapping: G lanes (16 or 32) of a wave own one subset; lane i holds row i of
+// W = [A[:,S] | b] in registers (column index static).  Partial pivoting is a
+// G-lane butterfly arg-max; the pivot row is broadcast lane->group; rows are never
+// moved (a lane is simply marked used).  A (<= 4 KiB) sits in LDS with an odd row
+// stride so the row gather is bank-conflict-free.  Each group walks a contiguous
+// range of combination ranks: unrank once, then lexicographic successors.
+#include <cfloat>
+
+#include "enum_problem.hpp"
+
+namespace {
+
+struct GroupBest {
+    double score;  // best score seen by this group (score = z if maximize else -z)
+};
+
+template <int G>
+struct SubsetSolve {
+    double xrow;     // this lane's final rhs (value of the variable pivoted in this row)
+    int P[G];        // P[t] = group-relative lane that became the pivot row of step t
+    bool singular;
+    bool feasible;
+};
+
+// Lexicographic unranking of `rank` into the sorted subset S (combinatorial number system).
+template <int G>
+__device__ __forceinline__ void unrank_subset(const EnumDev& d, unsigned long long rank, int (&S)[G]) {
+    int a = 0;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        S[t] = 0;
+        if (t < d.m) {
+            int j = a;
+            for (;; ++j) {
+                const unsigned long long cnt = d.binom[(d.n - 1 - j) * kBinomK + (d.m - 1 - t)];
+                if (rank < cnt) break;
+                rank -= cnt;
+            }
+            S[t] = j;
+            a = j + 1;
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void next_subset(int m, int n, int (&S)[G]) {
+    int tpos = -1;
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+        if (t < m && S[t] < n - m + t) tpos = t;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        if (t == tpos)
+            S[t] += 1;
+        else if (t > tpos && t < m && t > 0)
+            S[t] = S[t - 1] + 1;
+    }
+}
+
+// Gauss-Jordan with partial pivoting on [A[:,S] | b]; see orc_enum_subset for the
+// operation order this replays.
+template <int G>
+__device__ __forceinline__ void solve_subset(const EnumDev& d, const double* sA, const double* sb,
+                                             const int (&S)[G], int gl /* lane in group */,
+                                             SubsetSolve<G>& out) {
+    const int m = d.m;
+    const bool active = gl < m;
+    double W[G];
+#pragma unroll
+    for (int t = 0; t < G; ++t) W[t] = (active && t < m) ? sA[gl * d.lda + S[t]] : 0.0;
+    double rhs = active ? sb[gl] : 0.0;
+    bool used = !active;
+    bool sing = false;
+    double minp = INFINITY, maxp = 0.0;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        out.P[t] = 0;
+        if (t < m) {
+            double a = used ? -1.0 : fabs(W[t]);
+            int idx = gl;
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                const double oa = __shfl_xor(a, off, G);
+                const int oi = __shfl_xor(idx, off, G);
+                if (oa > a || (oa == a && oi < idx)) {
+                    a = oa;
+                    idx = oi;
+                }
+            }
+            const int p = idx;
+            if (!(a > 0.0)) sing = true;
+            minp = fmin(minp, a);
+            maxp = fmax(maxp, a);
+            const double piv = __shfl(W[t], p, G);
+            const double inv = 1.0 / piv;
+            const double l = -(W[t] * inv);
+            const bool isp = (gl == p);
+#pragma unroll
+            for (int c = t + 1; c < G; ++c) {
+                if (c < m) {
+                    const double pc = __shfl(W[c], p, G);
+                    W[c] = isp ? pc * inv : fma(l, pc, W[c]);
+                }
+            }
+            const double pr = __shfl(rhs, p, G);
+            rhs = isp ? pr * inv : fma(l, pr, rhs);
+            if (isp) used = true;
+            out.P[t] = p;
+        }
+    }
+    if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
+    out.singular = sing;
+    out.xrow = rhs;
+    const bool ok = !active || (rhs >= -1e-9);  // Canonical.cpp:171; NaN is infeasible
+    const unsigned long long bal = __ballot(ok);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << (lane & ~(G - 1)));
+    out.feasible = (bal & gmask) == gmask;
+}
+
+template <int G>
+__device__ __forceinline__ double subset_objective(const EnumDev& d, const double* sc,
+                                                   const int (&S)[G], const SubsetSolve<G>& s) {
+    double z = 0.0;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        if (t < d.m) {
+            const double xv = __shfl(s.xrow, s.P[t], G);
+            z = fma(sc[S[t]], xv, z);  // Canonical.cpp:86, ascending column order
+        }
+    }
+    return z;
+}
+
+__device__ __forceinline__ void stage_problem(const EnumDev& d, double* sA, double* sb, double* sc) {
+    for (int k = threadIdx.x; k < d.m * d.lda; k += blockDim.x) sA[k] = d.A[k];
+    for (int k = threadIdx.x; k < d.m; k += blockDim.x) sb[k] = d.b[k];
+    for (int k = threadIdx.x; k < d.n; k += blockDim.x) sc[k] = d.c[k];
+    __syncthreads();
+}
+
+// MODE 0: pass 1 (best score + counts + per-chunk best); MODE 1: pass 2 (first rank
+// with score >= star - tol).
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void k_enum_direct(EnumDev d, unsigned long long begin,
+                                                     unsigned long long end,
+                                                     unsigned long long per_chunk, double star,
+                                                     double tol) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sA = smem;
+    double* sb = sA + d.m * d.lda;
+    double* sc = sb + d.m;
+    unsigned long long* sred = reinterpret_cast<unsigned long long*>(sc + d.n);  // 4 words
+    if (threadIdx.x < 4) sred[threadIdx.x] = (threadIdx.x == 0) ? lp_f64_key(-INFINITY) : 0ULL;
+    stage_problem(d, sA, sb, sc);
+
+    const int gl = threadIdx.x & (G - 1);
+    const unsigned long long chunk =
+        (unsigned long long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+    unsigned long long k0 = begin + chunk * per_chunk;
+    unsigned long long k1 = k0 + per_chunk;
+    if (k1 > end) k1 = end;
+
+    double best = -INFINITY;
+    unsigned long long cnt0 = 0, cnt1 = 0, cnt2 = 0;
+    unsigned long long first = ~0ULL;
+    if (k0 < k1) {  // uniform per group; groups of one wave may diverge here
+        int S[G];
+        unrank_subset<G>(d, k0, S);
+        for (unsigned long long k = k0; k < k1; ++k) {
+            SubsetSolve<G> s;
+            solve_subset<G>(d, sA, sb, S, gl, s);
+            if (s.singular) {
+                ++cnt2;
+            } else if (!s.feasible) {
+                ++cnt1;
+            } else {
+                ++cnt0;
+                const double z = subset_objective<G>(d, sc, S, s);
+                const double score = d.maximize ? z : -z;
+                if (MODE == 0) {
+                    if (score > best) best = score;
+                } else {
+                    if (score >= star - tol && first == ~0ULL) first = k;
+                }
+            }
+            next_subset<G>(d.m, d.n, S);
+        }
+    }
+    if (MODE == 0) {
+        if (gl == 0) {
+            if (k0 < end) d.chunk_best[chunk] = best;
+            atomicMax(&sred[0], lp_f64_key(best));
+            if (cnt0) atomicAdd(&sred[1], cnt0);
+            if (cnt1) atomicAdd(&sred[2], cnt1);
+            if (cnt2) atomicAdd(&sred[3], cnt2);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMax(&d.result->best_key, sred[0]);
+            if (sred[1]) atomicAdd(&d.result->counts[0], sred[1]);
+            if (sred[2]) atomicAdd(&d.result->counts[1], sred[2]);
+            if (sred[3]) atomicAdd(&d.result->counts[2], sred[3]);
+        }
+    } else {
+        if (gl == 0 && first != ~0ULL) atomicMin(&d.result->first_rank, first);
+    }
+}
+
+// One subset, one group: writes xB (by sorted column), the subset, objective, verdict.
+template <int G>
+__global__ __launch_bounds__(64) void k_enum_vertex(EnumDev d, unsigned long long rank, double* vx,
+                                                    int* vi) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sA = smem;
+    double* sb = sA + d.m * d.lda;
+    double* sc = sb + d.m;
+    stage_problem(d, sA, sb, sc);
+    if (threadIdx.x >= G) return;
+    const int gl = threadIdx.x;
+    int S[G];
+    unrank_subset<G>(d, rank, S);
+    SubsetSolve<G> s;
+    solve_subset<G>(d, sA, sb, S, gl, s);
+    const double z = subset_objective<G>(d, sc, S, s);
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        if (t < d.m) {
+            const double xv = __shfl(s.xrow, s.P[t], G);
+            if (gl == 0) {
+                vx[t] = xv;
+                vi[t] = S[t];
+            }
+        }
+    }
+    if (gl == 0) {
+        vx[kEnumMaxM] = z;
+        vi[kEnumMaxM] = s.singular ? LP_SUBSET_SINGULAR
+                                   : (s.feasible ? LP_SUBSET_FEASIBLE : LP_SUBSET_INFEASIBLE);
+    }
+}
+
+size_t enum_smem_bytes(const EnumDev& d) {
+    return sizeof(double) * (size_t)(d.m * d.lda + d.m + d.n) + 4 * sizeof(unsigned long long) + 16;
+}
+
+}  // namespace
+
+template <int MODE>
+static int launch_direct(lp_enum_problem* p, uint64_t begin, uint64_t end, double star, double tol,
+                         uint64_t* per_chunk_out, int* chunks_out) {
+    lp_context* ctx = p->ctx;
+    const EnumDev& d = p->dev;
+    const int G = d.m <= 16 ? 16 : 32;
+    const int block = 256;
+    const int groups_per_block = block / G;
+    const uint64_t count = end - begin;
+    // enough groups to fill the chip several times over, but at least ~64 subsets per group
+    uint64_t want_groups = (uint64_t)ctx->num_cus * 8 * groups_per_block;
+    if (want_groups > (uint64_t)p->chunk_cap) want_groups = p->chunk_cap;
+    uint64_t per_chunk = lp_ceil_div<uint64_t>(count, want_groups);
+    if (per_chunk < 64) per_chunk = 64;
+    const uint64_t chunks = lp_ceil_div<uint64_t>(count, per_chunk);
+    const unsigned grid = (unsigned)lp_ceil_div<uint64_t>(chunks, groups_per_block);
+    const size_t shm = enum_smem_bytes(d);
+    if (G == 16)
+        hipLaunchKernelGGL((k_enum_direct<16, MODE>), grid, block, shm, ctx->stream, d, begin, end,
+                           per_chunk, star, tol);
+    else
+        hipLaunchKernelGGL((k_enum_direct<32, MODE>), grid, block, shm, ctx->stream, d, begin, end,
+                           per_chunk, star, tol);
+    if (per_chunk_out) *per_chunk_out = per_chunk;
+    if (chunks_out) *chunks_out = (int)chunks;
+    return LP_OPTIMAL;
+}
+
+static int reset_result(lp_enum_problem* p) {
+    EnumResult r;
+    std::memset(&r, 0, sizeof(r));
+    r.best_key = lp_f64_key(-INFINITY);
+    r.first_rank = ~0ULL;
+    *p->h_result = r;
+    LP_HIP(p->ctx, hipMemcpyAsync(p->dev.result, p->h_result, sizeof(r), hipMemcpyHostToDevice,
+                                  p->ctx->stream));
+    return LP_OPTIMAL;
+}
+
+static int fetch_result(lp_enum_problem* p) {
+    LP_HIP(p->ctx, hipMemcpyAsync(p->h_result, p->dev.result, sizeof(EnumResult),
+                                  hipMemcpyDeviceToHost, p->ctx->stream));
+    LP_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    LP_HIP(p->ctx, hipGetLastError());
+    return LP_OPTIMAL;
+}
+
+int lp_enum_direct_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                         uint64_t counts[3], lp_enum_stats* stats) {
+    lp_context* ctx = p->ctx;
+    int rc = reset_result(p);
+    if (rc) return rc;
+    uint64_t per_chunk = 0;
+    int chunks = 0;
+    LP_HIP(ctx, hipEventRecord(p->ev0, ctx->stream));
+    if (end > begin) launch_direct<0>(p, begin, end, 0.0, 0.0, &per_chunk, &chunks);
+    LP_HIP(ctx, hipEventRecord(p->ev1, ctx->stream));
+    rc = fetch_result(p);
+    if (rc) return rc;
+    float ms = 0.f;
+    LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_begin = begin;
+    p->last_end = end;
+    p->last_per_chunk = per_chunk;
+    p->last_chunks = chunks;
+    *score_best = lp_key_f64(p->h_result->best_key);
+    for (int k = 0; k < 3; ++k) counts[k] = p->h_result->counts[k];
+    if (stats) {
+        stats->kernel_ms = ms;
+        stats->subsets = end - begin;
+        stats->launches = end > begin ? 1 : 0;
+    }
+    return LP_OPTIMAL;
+}
+
+int lp_enum_direct_first(lp_enum_problem* p, uint64_t begin, uint64_t end, double score_star,
+                         double tol, uint64_t* rank_out) {
+    lp_context* ctx = p->ctx;
+    *rank_out = UINT64_MAX;
+    if (end <= begin) return LP_OPTIMAL;
+    // Narrow to the first chunk of the cached pass 1 whose best score qualifies.
+    if (begin == p->last_begin && end == p->last_end && p->last_chunks > 0) {
+        p->h_chunk_best.resize((size_t)p->last_chunks);
+        LP_HIP(ctx, hipMemcpyAsync(p->h_chunk_best.data(), p->dev.chunk_best,
+                                   sizeof(double) * (size_t)p->last_chunks, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int g = 0;
+        while (g < p->last_chunks && !(p->h_chunk_best[(size_t)g] >= score_star - tol)) ++g;
+        if (g == p->last_chunks) return LP_OPTIMAL;
+        const uint64_t nb = begin + (uint64_t)g * p->last_per_chunk;
+        uint64_t ne = nb + p->last_per_chunk;
+        if (ne > end) ne = end;
+        begin = nb;
+        end = ne;
+    }
+    int rc = reset_result(p);
+    if (rc) return rc;
+    launch_direct<1>(p, begin, end, score_star, tol, nullptr, nullptr);
+    rc = fetch_result(p);
+    if (rc) return rc;
+    // the narrowing above invalidated the chunk cache geometry for a second narrowing
+    *rank_out = p->h_result->first_rank;
+    return LP_OPTIMAL;
+}
+
+int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* subset, double* z,
+                          int* verdict) {
+    lp_context* ctx = p->ctx;
+    const EnumDev& d = p->dev;
+    const size_t shm = enum_smem_bytes(d);
+    if (d.m <= 16)
+        hipLaunchKernelGGL((k_enum_vertex<16>), 1, 64, shm, ctx->stream, d, rank, p->dvx, p->dvi);
+    else
+        hipLaunchKernelGGL((k_enum_vertex<32>), 1, 64, shm, ctx->stream, d, rank, p->dvx, p->dvi);
+    double hx[kEnumMaxM + 1];
+    int hi[kEnumMaxM + 1];
+    LP_HIP(ctx, hipMemcpyAsync(hx, p->dvx, sizeof(hx), hipMemcpyDeviceToHost, ctx->stream));
+    LP_HIP(ctx, hipMemcpyAsync(hi, p->dvi, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
+    LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LP_HIP(ctx, hipGetLastError());
+    for (int t = 0; t < d.m; ++t) {
+        xB[t] = hx[t];
+        subset[t] = hi[t];
+    }
+    *z = hx[kEnumMaxM];
+    *verdict = hi[kEnumMaxM];
+    return LP_OPTIMAL;
+}

@@ -1,0 +1,76 @@
+// enum_problem.hpp — device-side state of one vertex enumeration.
+#pragma once
+
+#include "lp_internal.hpp"
+
+constexpr int kEnumMaxN = 64;   // ranks must fit u64: C(64,32) < 2^64
+constexpr int kEnumMaxM = 32;
+constexpr int kBinomK = kEnumMaxM + 2;  // columns of the binomial table
+
+// Monotone double -> u64 key (so atomicMax on the key is max on the double).
+__host__ __device__ inline unsigned long long lp_f64_key(double v) {
+    unsigned long long b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (unsigned long long)__double_as_longlong(v);
+#else
+    std::memcpy(&b, &v, sizeof(b));
+#endif
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ inline double lp_key_f64(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b);
+#else
+    double v;
+    std::memcpy(&v, &b, sizeof(v));
+    return v;
+#endif
+}
+
+// Results of one pass, accumulated with device-scope atomics.
+struct EnumResult {
+    unsigned long long best_key;    // key of the best score (score = z if maximize else -z)
+    unsigned long long counts[3];   // feasible, infeasible, singular
+    unsigned long long first_rank;  // pass 2: smallest qualifying rank
+    unsigned long long pad[3];
+};
+
+struct EnumDev {
+    int m, n, lda;                  // lda = n + 1 (odd stride: conflict-free row gathers)
+    int maximize;
+    const double* A;                // m x lda row-major copy of the canonical A (pad column 0)
+    const double* b;                // m
+    const double* c;                // n
+    const unsigned long long* binom;  // (kEnumMaxN+1) x kBinomK table, C(i,k)
+    EnumResult* result;
+    double* chunk_best;             // per-chunk best score of the last pass 1
+};
+
+struct lp_enum_problem {
+    lp_context* ctx = nullptr;
+    EnumDev dev{};
+    double* dA = nullptr;
+    double* db = nullptr;
+    double* dc = nullptr;
+    unsigned long long* dbinom = nullptr;
+    std::vector<double> hA, hb, hc;  // host copies (column-major A) for argument checks only
+    EnumResult* h_result = nullptr;  // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // chunking of the last lp_enum_range call (pass 2 narrows to the first qualifying chunk)
+    uint64_t last_begin = 0, last_end = 0, last_per_chunk = 0;
+    int last_chunks = 0;
+    int chunk_cap = 0;
+    std::vector<double> h_chunk_best;
+    // vertex scratch
+    double* dvx = nullptr;  // kEnumMaxM xB values + 1 objective
+    int* dvi = nullptr;     // kEnumMaxM subset + 1 verdict
+};
+
+// enum_direct.hip
+int lp_enum_direct_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                         uint64_t counts[3], lp_enum_stats* stats);
+int lp_enum_direct_first(lp_enum_problem* p, uint64_t begin, uint64_t end, double score_star,
+                         double tol, uint64_t* rank_out);
+int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* subset, double* z,
+                          int* verdict);

@@ -1,0 +1,58 @@
+// simplex_problem.hpp — device-side state of one single-LP tableau solve.
+#pragma once
+
+#include "lp_internal.hpp"
+
+struct SimplexState {
+    int status;       // kRunning (-100) while pivoting, then an LP_* code
+    int iters;        // pivots executed (the reference's `iteration`, SimplexSolover.h:427)
+    int max_iter;     // MAX_ITER, :426
+    int enter;        // entering column of the pending pivot
+    int leave;        // leaving basis POSITION (= tableau row) of the pending pivot
+    int pivot_valid;  // 1 if select staged a pivot for the update kernel
+    int pad0, pad1;
+    double eps;       // Solver::EPS, :13
+    double minpiv, maxpiv;  // crash: smallest / largest |pivot|
+};
+
+// Everything the kernels need, passed by value.
+struct SimplexDev {
+    int m, n, ld;     // ld = padded row length of T (multiple of 8 doubles)
+    int maximize;
+    int trace_cap;
+    double* T;        // (m+1) x ld row-major tableau
+    double* lcol;     // m+1: eta column of F (:198-204); entry r holds 1/u_r
+    double* prow;     // ld: copy of the pivot row before the update
+    int* basis;       // m: N, basis by position (:419)
+    unsigned char* nonbasic;  // n: complement(n, N) as flags (:97-108)
+    unsigned char* rowused;   // m: crash bookkeeping
+    int* rowpos;      // m: crash — tableau row chosen for basis position t
+    int* trace_enter; // trace_cap
+    int* trace_leave;
+    SimplexState* state;
+};
+
+struct lp_simplex_problem {
+    lp_context* ctx = nullptr;
+    SimplexDev dev{};
+    int n_orig = 0;
+    size_t tableau_bytes = 0;
+    double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset
+    double* dscratchT = nullptr;  // scratch copy used by the update micro-benchmark
+    int* dbasis0 = nullptr;
+    unsigned char* dnonbasic0 = nullptr;
+    double* dx = nullptr;         // n: extracted vertex
+    SimplexState* h_state = nullptr;  // pinned
+    std::vector<double> h_c;      // objective coefficients (Canonical::Evaluate on the host)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int init_status = LP_OPTIMAL; // LP_SINGULAR if the initial basis was singular
+    int last_status = -100;
+    int last_iters = 0;
+};
+
+// simplex_launch.hip
+void lp_simplex_launch_update(lp_simplex_problem* p);
+int lp_simplex_crash(lp_simplex_problem* p);
+int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
+int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
+int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, float* ms_out);

@@ -1,0 +1,94 @@
+"""world_size-2 (and 3) gloo runs of the sharded-enumeration driver on the CPU: the per-shard
+work is done by the oracle here, so what is under test is the sharding + reduction logic that
+bench.py and the multi-GPU path use (simplexmethod_amd/dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, seed, m, n, maximize, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import pyoracle as o
+    from simplexmethod_amd import dist as lpdist
+    from tests import lpcases
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+
+    def range_fn(lo, hi):
+        st, z, counts = o.enum_range(A, b, c, maximize, lo, hi)
+        return z, counts
+
+    def first_fn(lo, hi, zstar, tol):
+        return o.enum_first_within(A, b, c, maximize, lo, hi, zstar, tol)
+
+    res = lpdist.enum_solve_sharded(lpdist.TorchComm("cpu"), total, maximize, range_fn, first_fn)
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("maximize", [True, False])
+def test_sharded_enumeration_gloo(world, maximize):
+    import torch.multiprocessing as mp
+    from oracle import pyoracle as o
+    from tests import lpcases
+    seed, m, n = 17, 5, 12
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    ref = o.enum_solve(A, b, c, maximize, n)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, m, n, maximize, out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len(out) == world
+    for r in range(world):
+        res = out[r]
+        assert res["feasible"] and res["rank"] == ref["rank"] and res["counts"] == ref["counts"]
+        assert res["zstar"] == ref["obj"] or abs(res["zstar"] - ref["obj"]) <= 1e-9
+
+
+def test_shard_bounds_cover_exactly():
+    from simplexmethod_amd import dist as lpdist
+    for total in (0, 1, 10, 601080390):
+        for world in (1, 2, 3, 8):
+            cuts = [lpdist.shard_bounds(total, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_local_comm_single_process():
+    from oracle import pyoracle as o
+    from simplexmethod_amd import dist as lpdist
+    from tests import lpcases
+    A, b, c, _, no = lpcases.input_symmetric_lp()
+    res = lpdist.enum_solve_sharded(
+        lpdist.LocalComm(), 10, True,
+        lambda lo, hi: o.enum_range(A, b, c, True, lo, hi)[1:],
+        lambda lo, hi, z, tol: o.enum_first_within(A, b, c, True, lo, hi, z, tol))
+    assert res == dict(feasible=True, zstar=35.0, rank=2, counts=[7, 3, 0])

@@ -1,0 +1,131 @@
+"""GPU parity: vertex enumeration (through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as o
+from simplexmethod_amd import capi
+from tests import lpcases
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = [capi.ENUM_DIRECT]
+
+
+def test_input_symmetric_table(ctx):
+    A, b, c, _, no = lpcases.input_symmetric_lp()
+    r = ctx.enum_solve(A, b, c, True, no)
+    assert r["status"] == 0 and r["rank"] == 2 and r["basis"].tolist() == [0, 3]
+    assert r["x"].tolist() == [5, 0, 0] and r["obj"] == 35 and r["counts"] == [7, 3, 0]
+    p = ctx.enum_problem(A, b, c, True)
+    for k in range(10):
+        st, xB, z = o.enum_subset(A, b, c, o.unrank(5, 2, k))
+        v = p.vertex(k)
+        assert v["verdict"] == st and v["basis"].tolist() == o.unrank(5, 2, k).tolist()
+        if st != o.SUBSET_SINGULAR:
+            assert np.array_equal(v["x"][v["basis"]], xB) and v["obj"] == z
+    p.free()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("seed,m,n", [(1, 1, 4), (2, 3, 7), (3, 5, 12), (4, 8, 16), (5, 10, 20),
+                                       (6, 14, 18), (7, 16, 19), (8, 17, 20), (9, 6, 6)])
+def test_enum_matches_oracle(ctx, algo, seed, m, n):
+    A, b, c, _ = lpcases.random_lp(seed, m, n) if n > m else (np.eye(m) * 2, np.ones(m), np.ones(m), None)
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, stats = p.range(0, total, algo)
+    assert rc == st and gcounts == counts and sum(gcounts) == total
+    if st == o.OPTIMAL:
+        assert gz == z                                       # bit for bit
+        k = o.enum_first_within(A, b, c, True, 0, total, z)
+        assert p.first_within(0, total, z) == k
+        v = p.vertex(k)
+        _, xB, zz = o.enum_subset(A, b, c, o.unrank(n, m, k))
+        assert v["obj"] == zz and np.array_equal(v["x"][v["basis"]], xB)
+    p.free()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_minimise_and_signed_data(ctx, algo):
+    rng = np.random.default_rng(5)
+    m, n = 6, 14
+    A = rng.normal(size=(m, n))
+    b = rng.normal(size=m)
+    c = rng.normal(size=n)
+    total = o.binom(n, m)
+    for maximize in (True, False):
+        st, z, counts = o.enum_range(A, b, c, maximize, 0, total)
+        p = ctx.enum_problem(A, b, c, maximize)
+        rc, gz, gcounts, _ = p.range(0, total, algo)
+        assert rc == st and gcounts == counts and gz == z
+        assert p.first_within(0, total, z) == o.enum_first_within(A, b, c, maximize, 0, total, z)
+        p.free()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_singular_subsets_counted(ctx, algo):
+    # duplicate and zero columns -> many singular bases
+    rng = np.random.default_rng(9)
+    m, n = 4, 10
+    A = rng.uniform(size=(m, n))
+    A[:, 3] = A[:, 1]
+    A[:, 7] = 0.0
+    b = rng.uniform(1, 2, size=m)
+    c = rng.uniform(size=n)
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    assert counts[2] > 0
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, _ = p.range(0, total, algo)
+    assert gcounts == counts and gz == z
+    p.free()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_shards_compose(ctx, algo):
+    """The rank space shards across GPUs: any split gives the same answer."""
+    A, b, c, _ = lpcases.random_lp(12, 7, 16)
+    total = o.binom(16, 7)
+    p = ctx.enum_problem(A, b, c, True)
+    _, z, counts, _ = p.range(0, total, algo)
+    for parts in (2, 3, 8):
+        cuts = [total * k // parts for k in range(parts + 1)]
+        zs, cs, firsts = [], np.zeros(3, dtype=np.int64), []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            _, zz, cc, _ = p.range(lo, hi, algo)
+            zs.append(zz)
+            cs += cc
+        assert max(zs) == z and cs.tolist() == counts
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            p.range(lo, hi, algo)
+            firsts.append(p.first_within(lo, hi, z))
+        assert min(firsts) == o.enum_first_within(A, b, c, True, 0, total, z)
+    # empty shard
+    rc, zz, cc, _ = p.range(5, 5, algo)
+    assert rc == capi.INFEASIBLE and cc == [0, 0, 0] and zz == -np.inf
+    p.free()
+
+
+def test_enumeration_agrees_with_simplex_on_gpu(ctx):
+    """README.md:42 — cross-check of the two solvers, both on the GPU."""
+    for seed, m, n in [(31, 4, 9), (32, 6, 13), (33, 8, 17)]:
+        A, b, c, basis = lpcases.random_lp(seed, m, n)
+        s = ctx.simplex_solve(A, b, c, basis, True, n - m)
+        e = ctx.enum_solve(A, b, c, True, n - m)
+        assert s["status"] == e["status"] == 0
+        assert abs(e["obj"] - s["obj"]) <= 1e-10 * abs(s["obj"])
+        np.testing.assert_allclose(e["x"], s["x"], rtol=1e-9, atol=1e-10)
+        assert sorted(s["basis"].tolist()) == e["basis"].tolist()
+
+
+def test_bad_arguments(ctx):
+    A, b, c, _ = lpcases.random_lp(1, 3, 7)
+    p = ctx.enum_problem(A, b, c, True)
+    with pytest.raises(capi.LPError):
+        p.range(0, p.total + 1)
+    with pytest.raises(capi.LPError):
+        p.vertex(p.total)
+    p.free()
+    with pytest.raises(capi.LPError):
+        ctx.enum_problem(np.ones((40, 70)), np.ones(40), np.ones(70))

@@ -1,0 +1,145 @@
+"""GPU parity: the HIP simplex path (through the C ABI) against the oracle's tableau
+restatement — bit-exact pivots, basis, tableau and vertex — and against the reference-shaped
+restatement within the north star's 1e-10."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as o
+from simplexmethod_amd import capi
+from tests import lpcases
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, A, b, c, basis, maximize, n_orig, trace_cap=1 << 14, max_iter=capi.MAX_ITER,
+         algo=capi.SIMPLEX_AUTO):
+    p = ctx.simplex_problem(A, b, c, basis, maximize, n_orig)
+    rc, st = p.run(max_iter=max_iter, algo=algo)
+    out = p.download(trace_cap=min(trace_cap, max(st.pivots, 1)), want_tableau=True)
+    p.free()
+    out.update(status=rc, iters=st.pivots)
+    return out
+
+
+def _assert_bit_exact(g, r):
+    assert g["status"] == r["status"]
+    assert g["iters"] == r["iters"]
+    k = r["iters"]
+    assert list(zip(g["trace_enter"][:k].tolist(), g["trace_leave"][:k].tolist())) == r["trace"][:k]
+    assert np.array_equal(g["basis"], r["basis"])
+    if r["status"] == o.OPTIMAL:
+        assert np.array_equal(g["x"], r["x"])        # bit for bit
+        assert g["obj"] == r["obj"]
+    if r["tableau"] is not None and r["status"] in (o.OPTIMAL, o.ITER_LIMIT, o.UNBOUNDED):
+        assert np.array_equal(g["tableau"], r["tableau"])
+
+
+def test_known_answers(ctx):
+    A, b, c, basis, no = lpcases.main_cpp_lp()
+    r = ctx.simplex_solve(A, b, c, basis, True, no)
+    assert r["status"] == 0 and r["x"].tolist() == [0, 0, 6] and r["obj"] == 24
+    assert r["basis"].tolist() == [2, 4] and r["iters"] == 1
+    A, b, c, basis, no = lpcases.input_symmetric_lp()
+    r = ctx.simplex_solve(A, b, c, basis, True, no)
+    assert r["status"] == 0 and r["x"].tolist() == [5, 0, 0] and r["obj"] == 35
+    assert r["basis"].tolist() == [3, 0] and r["iters"] == 2
+
+
+@pytest.mark.parametrize("seed,m,n", [(0, 2, 5), (1, 8, 16), (2, 16, 32), (3, 33, 71),
+                                       (4, 64, 128), (5, 128, 256), (6, 100, 1500)])
+def test_random_lp_bit_exact(ctx, seed, m, n):
+    A, b, c, basis = lpcases.random_lp(seed, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, True, n - m)
+    assert r["status"] == o.OPTIMAL and r["iters"] > 0
+    _assert_bit_exact(g, r)
+
+
+def test_baseline_config_512x1024(ctx):
+    """BASELINE.json configs[1]: m=512, n=1024, seed 0."""
+    m, n = 512, 1024
+    A, b, c, basis = lpcases.random_lp(0, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, True, n - m)
+    _assert_bit_exact(g, r)
+    # size-independent properties of the final tableau: basic columns are exact unit
+    # vectors, reduced costs of an optimum are <= eps, xB >= 0 up to rounding
+    T = g["tableau"]
+    for t, j in enumerate(g["basis"]):
+        col = T[:m, j]
+        assert col[t] == 1.0 and np.count_nonzero(col) == 1 and T[m, j] == 0.0
+    assert T[m, :n].max() <= 1e-9
+    assert T[:m, n].min() >= -1e-9
+    xfull = np.zeros(n)
+    xfull[g["basis"]] = T[:m, n]
+    np.testing.assert_allclose(A @ xfull, b, rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed,m,n", [(7, 16, 32), (8, 48, 96)])
+def test_against_reference_shaped_oracle(ctx, seed, m, n):
+    """North star: basis indices exact, objective / vertex within 1e-10 relative of the path
+    that recomputes Binv by full-pivot LU every iteration (SimplexSolover.h:446)."""
+    A, b, c, basis = lpcases.random_lp(seed, m, n)
+    r = o.simplex_reference(A, b, c, basis, True, n - m, trace_cap=4096)
+    g = ctx.simplex_solve(A, b, c, basis, True, n - m)
+    assert g["status"] == r["status"] == 0 and g["iters"] == r["iters"]
+    assert np.array_equal(g["basis"], r["basis"])
+    np.testing.assert_allclose(g["x"], r["x"], rtol=1e-10, atol=1e-12)
+    assert abs(g["obj"] - r["obj"]) <= 1e-10 * abs(r["obj"])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+@pytest.mark.parametrize("maximize", [True, False])
+def test_general_basis_crash_and_minimise(ctx, seed, maximize):
+    """Non-slack initial basis (computeBFS, SimplexSolover.h:423) and the minimise rules
+    (:163-174)."""
+    A, b, c, basis = lpcases.general_lp(seed, 9, 20)
+    n = A.shape[1]
+    r = o.simplex_tableau(A, b, c, basis, maximize, n, trace_cap=4096, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, maximize, n)
+    assert r["status"] == o.OPTIMAL
+    _assert_bit_exact(g, r)
+
+
+def test_status_codes(ctx):
+    A = np.array([[1.0, -1.0, 1.0]])
+    assert ctx.simplex_solve(A, [1.0], [1.0, 1.0, 0.0], [2], True, 2)["status"] == capi.UNBOUNDED
+    A = np.array([[4, 3, 0, 1], [0, 4, 0, 4.0]])   # main.cpp:24-34 (commented-out LP), basis {0,2}
+    assert ctx.simplex_solve(A, [4, 6.0], [5, 1, 0, 0.0], [0, 2], False, 4)["status"] == capi.SINGULAR
+    A, b, c, basis = lpcases.random_lp(5, 16, 32)
+    r = o.simplex_tableau(A, b, c, basis, True, 16, max_iter=3, trace_cap=8, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, True, 16, max_iter=3)
+    assert g["status"] == capi.ITER_LIMIT
+    _assert_bit_exact(g, r)
+    with pytest.raises(capi.LPError):
+        ctx.simplex_solve(A, b, c, [0] * 15 + [99], True, 16)
+    with pytest.raises(capi.LPError):
+        ctx.simplex_solve(A, b, c, basis, True, 0)
+
+
+def test_degenerate_ties(ctx):
+    """Degenerate vertex: several ratios tie at 0 — the scan must keep the FIRST
+    (SimplexSolover.h:187 uses r < theta - EPS)."""
+    A = np.array([[1, 1, 1, 0, 0], [1, 2, 0, 1, 0], [2, 1, 0, 0, 1.0]])
+    b = np.array([0.0, 0.0, 4.0])
+    c = np.array([3, 2, 0, 0, 0.0])
+    basis = np.array([2, 3, 4], dtype=np.int32)
+    r = o.simplex_tableau(A, b, c, basis, True, 2, trace_cap=64, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, True, 2)
+    _assert_bit_exact(g, r)
+
+
+def test_reset_and_repeat(ctx):
+    A, b, c, basis = lpcases.random_lp(9, 40, 90)
+    p = ctx.simplex_problem(A, b, c, basis, True, 50)
+    rc1, s1 = p.run()
+    d1 = p.download()
+    p.reset()
+    rc2, s2 = p.run()
+    d2 = p.download()
+    assert rc1 == rc2 == 0 and s1.pivots == s2.pivots
+    assert np.array_equal(d1["x"], d2["x"]) and np.array_equal(d1["basis"], d2["basis"])
+    p.reset()
+    ms = p.bench_update(0, 0, 10)   # A[0,0] ~ U(0,1): a valid pivot element
+    assert ms > 0
+    p.free()
