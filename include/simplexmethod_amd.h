@@ -87,7 +87,8 @@ typedef struct lp_simplex_problem lp_simplex_problem;
 enum {
     LP_SIMPLEX_ALGO_AUTO = 0,
     LP_SIMPLEX_ALGO_LAUNCH = 1,    /* one select + one rank-1-update launch per pivot   */
-    LP_SIMPLEX_ALGO_PERSISTENT = 2 /* whole solve in one cooperative persistent launch  */
+    LP_SIMPLEX_ALGO_LOOKAHEAD = 2  /* J pivots staged by a one-workgroup selector, then
+                                      one rank-J update pass over the tableau            */
 };
 
 typedef struct lp_simplex_stats {

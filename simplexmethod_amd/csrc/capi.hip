@@ -120,6 +120,8 @@ void lp_simplex_free(lp_simplex_problem* p) {
     (void)hipFree(d.trace_enter); (void)hipFree(d.trace_leave); (void)hipFree(d.state);
     (void)hipFree(p->dT0); (void)hipFree(p->dscratchT); (void)hipFree(p->dbasis0);
     (void)hipFree(p->dnonbasic0); (void)hipFree(p->dx);
+    (void)hipFree(p->look.etaL); (void)hipFree(p->look.etaP); (void)hipFree(p->look.dvec);
+    (void)hipFree(p->look.rhs); (void)hipFree(p->look.piv); (void)hipFree(p->look.count);
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -173,6 +175,19 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
     LP_TRY(hipHostMalloc(&p->h_state, sizeof(SimplexState)));
     LP_TRY(hipEventCreate(&p->ev0));
     LP_TRY(hipEventCreate(&p->ev1));
+    {
+        LookDev& la = p->look;
+        la.J = lp_lookahead_pick_j(m, n);
+        la.rows_pad = ((m + 1 + 7) / 8) * 8;
+        const size_t J = (size_t)(la.J > 0 ? la.J : 1);
+        LP_TRY(hipMalloc(&la.etaL, sizeof(double) * J * (size_t)la.rows_pad));
+        LP_TRY(hipMalloc(&la.etaP, sizeof(double) * J * (size_t)d.ld));
+        LP_TRY(hipMalloc(&la.dvec, sizeof(double) * (size_t)d.ld));
+        LP_TRY(hipMalloc(&la.rhs, sizeof(double) * (size_t)la.rows_pad));
+        LP_TRY(hipMalloc(&la.piv, sizeof(int) * 2 * J));
+        LP_TRY(hipMalloc(&la.count, sizeof(int)));
+        LP_TRY(hipMemsetAsync(la.count, 0, sizeof(int), ctx->stream));
+    }
 
     // Initial tableau [A | b] with the cost row c underneath, row-major (host-side O(mn)
     // layout change: Eigen's column-major A -> rows that the update kernel streams).
@@ -246,10 +261,18 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
         p->last_status = p->init_status;
         return p->init_status;
     }
+    if (algo == LP_SIMPLEX_ALGO_AUTO)
+        algo = p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD : LP_SIMPLEX_ALGO_LAUNCH;
     switch (algo) {
-        case LP_SIMPLEX_ALGO_AUTO:
         case LP_SIMPLEX_ALGO_LAUNCH:
             return lp_simplex_run_launch(p, eps, max_iter, stats_out);
+        case LP_SIMPLEX_ALGO_LOOKAHEAD: {
+            if (p->look.J < 1)
+                LP_FAIL(ctx, LP_BAD_ARG, "look-ahead selector does not fit LDS for this m, n");
+            int rc = lp_lookahead_prepare(p);
+            if (rc) return rc;
+            return lp_simplex_run_lookahead(p, eps, max_iter, stats_out);
+        }
         default:
             LP_FAIL(ctx, LP_BAD_ARG, "unknown simplex algorithm id");
     }

@@ -1,0 +1,364 @@
+// simplex_lookahead.hip — single-LP tableau simplex with J-pivot look-ahead
+// (LP_SIMPLEX_ALGO_PERSISTENT's successor; selected by LP_SIMPLEX_ALGO_AUTO).
+//
+// Same pivot rules as simplex_launch.hip (/root/reference/src/SimplexSolover.h:152-196)
+// and bit-identical tableau values, but the 4.2 MB tableau is read and written once per
+// J pivots instead of once per pivot:
+//
+//   selector (ONE workgroup):  chooses J consecutive pivots.  Everything a pivot rule
+//     needs — the reduced-cost row, xB, the entering column, the pivot row — is O(m+n)
+//     data; it is obtained from the STALE tableau in HBM plus the etas staged so far in
+//     this batch (kept in LDS), applying to each needed element exactly the fma sequence
+//     the update would have applied.  The reduced-cost row and xB live in LDS across the
+//     batch.  Output: J eta columns (F of SimplexSolover.h:198-204) and J pivot rows.
+//   rank-J update (whole chip): every tableau element takes its J fused multiply-adds
+//     in pivot order in registers — one HBM read + one write per J pivots, and the same
+//     bits as J successive rank-1 updates (each element's operation sequence is
+//     unchanged).
+//
+// Algorithmic bytes stay 16*m*(n+1) per pivot; HBM traffic per pivot
+// drops by J.
+#include "device_select.hpp"
+#include "lp_internal.hpp"
+#include "simplex_problem.hpp"
+
+namespace {
+
+constexpr int kRunning = -100;
+constexpr int SEL_THREADS = 1024;
+
+// LDS carve of the selector (all in the dynamic region, 16-B aligned pieces)
+struct SelLds {
+    double* d;      // n+1 : reduced-cost row (entry n = -objective)
+    double* rhs;    // m   : xB
+    double* u;      // m   : entering column of the current tableau
+    double* lcH;    // J x m     : staged eta columns (entry r = 1/u_r)
+    double* prH;    // J x (n+1) : staged pivot rows (before scaling)
+    double* inv;    // J
+    double* f64;    // 4 scalars: ur, inv, lm, rhs_r
+    int* rq;        // J : leaving positions
+    int* eq;        // J : entering columns
+    int* i32;       // 4 scalars: enter, leave
+    unsigned char* nb;  // n : non-basic flags
+};
+
+__host__ __device__ inline size_t sel_lds_bytes(int m, int n, int J) {
+    size_t dbl = (size_t)(n + 1) + 2 * (size_t)m + (size_t)J * ((size_t)m + n + 1) + J + 4;
+    dbl = (dbl + 1) & ~(size_t)1;
+    size_t bytes = dbl * 8 + (size_t)(2 * J + 4) * 4;
+    bytes = (bytes + 15) & ~(size_t)15;
+    return bytes + (size_t)n + 16;
+}
+
+__device__ inline SelLds carve(double* base, int m, int n, int J) {
+    SelLds s;
+    s.d = base;
+    s.rhs = s.d + (n + 1);
+    s.u = s.rhs + m;
+    s.lcH = s.u + m;
+    s.prH = s.lcH + (size_t)J * m;
+    s.inv = s.prH + (size_t)J * (n + 1);
+    s.f64 = s.inv + J;
+    size_t dbl = (size_t)(n + 1) + 2 * (size_t)m + (size_t)J * ((size_t)m + n + 1) + J + 4;
+    dbl = (dbl + 1) & ~(size_t)1;
+    s.rq = reinterpret_cast<int*>(base + dbl);
+    s.eq = s.rq + J;
+    s.i32 = s.eq + J;
+    size_t bytes = dbl * 8 + (size_t)(2 * J + 4) * 4;
+    bytes = (bytes + 15) & ~(size_t)15;
+    s.nb = reinterpret_cast<unsigned char*>(base) + bytes;
+    return s;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookDev la) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    SimplexState* st = d.state;
+    const int tid = threadIdx.x;
+    if (st->status != kRunning) {
+        if (tid == 0) *la.count = 0;
+        return;
+    }
+    const int m = d.m, n = d.n, ld = d.ld, J = la.J;
+    SelLds s = carve(smem, m, n, J);
+    const double eps = st->eps;
+    const int max_iter = st->max_iter;
+    int iters = st->iters;
+    for (int j = tid; j <= n; j += SEL_THREADS) s.d[j] = la.dvec[j];
+    for (int j = tid; j < n; j += SEL_THREADS) s.nb[j] = d.nonbasic[j];
+    for (int i = tid; i < m; i += SEL_THREADS) s.rhs[i] = la.rhs[i];
+    __syncthreads();
+
+    int cnt = 0;
+    int status = kRunning;
+    const double* T = d.T;
+    for (int q0 = 0; q0 < J; ++q0) {
+        const int sidx = q0;  // index of the pivot being staged
+        if (iters >= max_iter) {  // SimplexSolover.h:429,:450
+            status = LP_ITER_LIMIT;
+            break;
+        }
+        // ---- pricing, :152-174, on the LDS-resident reduced-cost row
+        if (tid < 64) {
+            double best;
+            int e;
+            auto load = [&](int j, bool& ok) {
+                ok = s.nb[j] != 0;
+                return s.d[j];
+            };
+            if (d.maximize)
+                e = lpdev::wave_chain_select<true>(n, eps, best, load);
+            else
+                e = lpdev::wave_chain_select<false>(n, eps, best, load);
+            const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
+            if (tid == 0) s.i32[0] = optimal ? -1 : e;
+        }
+        __syncthreads();
+        const int e = s.i32[0];
+        if (e < 0) {
+            status = LP_OPTIMAL;
+            break;
+        }
+        // ---- entering column of the CURRENT tableau: stale column + staged etas (:176)
+        int any_pos = 0;
+        for (int i = tid; i < m; i += SEL_THREADS) {
+            double t = T[(size_t)i * ld + e];
+            for (int q = 0; q < sidx; ++q) {
+                const int rq = s.rq[q];
+                if (i == rq)
+                    t = t * s.inv[q];
+                else
+                    t = fma(s.lcH[(size_t)q * m + i], s.prH[(size_t)q * (n + 1) + e], t);
+                if (e == s.eq[q]) t = (i == rq) ? 1.0 : 0.0;
+            }
+            s.u[i] = t;
+            if (!(t <= eps)) any_pos = 1;  // :179
+        }
+        if (!__syncthreads_or(any_pos)) {
+            status = LP_UNBOUNDED;
+            break;
+        }
+        // ---- ratio test, :181-194
+        if (tid < 64) {
+            double theta;
+            auto load = [&](int i, bool& ok) {
+                const double ui = s.u[i];
+                ok = ui > eps;
+                return ok ? s.rhs[i] / ui : 0.0;
+            };
+            const int r = lpdev::wave_chain_select<false>(m, eps, theta, load);
+            if (tid == 0) {
+                s.i32[1] = r;
+                if (r >= 0) {
+                    const double ur = s.u[r];
+                    s.f64[0] = ur;
+                    s.f64[1] = 1.0 / ur;        // F(r,r), :204
+                    s.f64[2] = -s.d[e] / ur;    // F row of the reduced costs
+                    s.f64[3] = s.rhs[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int r = s.i32[1];
+        if (r < 0) {
+            status = LP_UNBOUNDED;
+            break;
+        }
+        const double ur = s.f64[0], inv = s.f64[1], lm = s.f64[2], rhs_r = s.f64[3];
+        // ---- pivot row of the CURRENT tableau (before scaling) + reduced-cost update
+        double* prS = s.prH + (size_t)sidx * (n + 1);
+        double* etaP = la.etaP + (size_t)sidx * ld;
+        for (int j = tid; j < n; j += SEL_THREADS) {
+            double t = T[(size_t)r * ld + j];
+            for (int q = 0; q < sidx; ++q) {
+                const int rq = s.rq[q];
+                if (r == rq)
+                    t = t * s.inv[q];
+                else
+                    t = fma(s.lcH[(size_t)q * m + r], s.prH[(size_t)q * (n + 1) + j], t);
+                if (j == s.eq[q]) t = (r == rq) ? 1.0 : 0.0;
+            }
+            prS[j] = t;
+            etaP[j] = t;
+            const double dj = fma(lm, t, s.d[j]);
+            s.d[j] = (j == e) ? 0.0 : dj;
+        }
+        // ---- eta column (:198-204) + xB update
+        double* lcS = s.lcH + (size_t)sidx * m;
+        double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
+        for (int i = tid; i < m; i += SEL_THREADS) {
+            const double l = (i == r) ? inv : -s.u[i] / ur;
+            lcS[i] = l;
+            etaL[i] = l;
+            s.rhs[i] = (i == r) ? rhs_r * inv : fma(l, rhs_r, s.rhs[i]);
+        }
+        if (tid == 0) {
+            prS[n] = rhs_r;
+            etaP[n] = rhs_r;
+            s.d[n] = fma(lm, rhs_r, s.d[n]);
+            etaL[m] = lm;
+            s.rq[sidx] = r;
+            s.eq[sidx] = e;
+            s.inv[sidx] = inv;
+            la.piv[2 * sidx] = e;
+            la.piv[2 * sidx + 1] = r;
+            const int old = d.basis[r];
+            d.basis[r] = e;  // :196
+            s.nb[e] = 0;
+            s.nb[old] = 1;
+            if (iters < d.trace_cap) {
+                d.trace_enter[iters] = e;
+                d.trace_leave[iters] = r;
+            }
+        }
+        ++iters;
+        ++cnt;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int j = tid; j <= n; j += SEL_THREADS) la.dvec[j] = s.d[j];
+    for (int j = tid; j < n; j += SEL_THREADS) d.nonbasic[j] = s.nb[j];
+    for (int i = tid; i < m; i += SEL_THREADS) la.rhs[i] = s.rhs[i];
+    if (tid == 0) {
+        *la.count = cnt;
+        st->iters = iters;
+        st->status = status;
+        st->pivot_valid = 0;
+    }
+}
+
+// rank-J update, in place: t <- eta_{count-1}( ... eta_0(t) ... ) per element.
+constexpr int LU_TX = 64;  // column pairs per block
+constexpr int LU_TY = 4;
+constexpr int LU_RPT = 2;  // rows per thread
+
+__global__ __launch_bounds__(LU_TX* LU_TY) void k_look_update(SimplexDev d, LookDev la) {
+    const int count = *la.count;
+    if (count == 0) return;
+    const int ld2 = d.ld >> 1;
+    const int jp = blockIdx.x * LU_TX + threadIdx.x;
+    if (jp >= ld2) return;
+    const int rows = d.m + 1;
+    const int i0 = (blockIdx.y * LU_TY + threadIdx.y) * LU_RPT;
+    double2* T2 = reinterpret_cast<double2*>(d.T);
+    double2 t[LU_RPT];
+#pragma unroll
+    for (int k = 0; k < LU_RPT; ++k)
+        if (i0 + k < rows) t[k] = T2[(size_t)(i0 + k) * ld2 + jp];
+    for (int q = 0; q < count; ++q) {
+        const int e = la.piv[2 * q], r = la.piv[2 * q + 1];
+        const double2 pr = reinterpret_cast<const double2*>(la.etaP + (size_t)q * d.ld)[jp];
+        const double* lq = la.etaL + (size_t)q * la.rows_pad;
+        const int je = e >> 1;
+#pragma unroll
+        for (int k = 0; k < LU_RPT; ++k) {
+            const int i = i0 + k;
+            if (i < rows) {
+                const double l = lq[i];
+                if (i == r) {
+                    t[k].x = t[k].x * l;
+                    t[k].y = t[k].y * l;
+                } else {
+                    t[k].x = fma(l, pr.x, t[k].x);
+                    t[k].y = fma(l, pr.y, t[k].y);
+                }
+                if (jp == je) {
+                    const double unit = (i == r) ? 1.0 : 0.0;
+                    if (e & 1) t[k].y = unit; else t[k].x = unit;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LU_RPT; ++k)
+        if (i0 + k < rows) T2[(size_t)(i0 + k) * ld2 + jp] = t[k];
+}
+
+// dvec <- row m of T, rhs <- column n of T (after upload / crash / reset)
+__global__ void k_look_init(SimplexDev d, LookDev la) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= d.n) la.dvec[k] = d.T[(size_t)d.m * d.ld + k];
+    if (k < d.m) la.rhs[k] = d.T[(size_t)k * d.ld + d.n];
+    if (k == 0) *la.count = 0;
+}
+
+__global__ void k_look_state_init(SimplexDev d, double eps, int max_iter) {
+    SimplexState* st = d.state;
+    st->status = kRunning;
+    st->iters = 0;
+    st->max_iter = max_iter;
+    st->enter = st->leave = -1;
+    st->pivot_valid = 0;
+    st->eps = eps;
+}
+
+}  // namespace
+
+// Largest J (<= 16) whose selector fits the 160 KiB LDS of one CU; 0 = does not fit.
+int lp_lookahead_pick_j(int m, int n) {
+    const size_t cap = 156 * 1024;
+    int J = 0;
+    for (int j = 1; j <= 16; ++j)
+        if (sel_lds_bytes(m, n, j) <= cap) J = j;
+    return J;
+}
+
+int lp_lookahead_prepare(lp_simplex_problem* p) {
+    // one-time opt-in to > 64 KiB of dynamic LDS for the selector
+    const size_t bytes = sel_lds_bytes(p->dev.m, p->dev.n, p->look.J);
+    LP_HIP(p->ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_look_select),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LP_OPTIMAL;
+}
+
+int lp_lookahead_init_vectors(lp_simplex_problem* p) {
+    const SimplexDev& d = p->dev;
+    const int span = (d.n + 1 > d.m) ? d.n + 1 : d.m;
+    hipLaunchKernelGGL(k_look_init, lp_ceil_div(span, 256), 256, 0, p->ctx->stream, d, p->look);
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter,
+                             lp_simplex_stats* stats) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    const LookDev& la = p->look;
+    hipStream_t s = ctx->stream;
+    const size_t shm = sel_lds_bytes(d.m, d.n, la.J);
+    const dim3 ugrid(lp_ceil_div(d.ld / 2, LU_TX), lp_ceil_div(d.m + 1, LU_TY * LU_RPT));
+    int launches = 0;
+    LP_HIP(ctx, hipEventRecord(p->ev0, s));
+    hipLaunchKernelGGL(k_look_state_init, 1, 1, 0, s, d, eps, max_iter);
+    lp_lookahead_init_vectors(p);
+    launches += 2;
+    int batches = 4;
+    int status = kRunning;
+    for (;;) {
+        for (int k = 0; k < batches; ++k) {
+            hipLaunchKernelGGL(k_look_select, 1, SEL_THREADS, shm, s, d, la);
+            hipLaunchKernelGGL(k_look_update, ugrid, dim3(LU_TX, LU_TY), 0, s, d, la);
+        }
+        launches += 2 * batches;
+        LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipStreamSynchronize(s));
+        status = p->h_state->status;
+        if (status != kRunning) break;
+        if (batches < 64) batches *= 2;
+    }
+    LP_HIP(ctx, hipEventRecord(p->ev1, s));
+    LP_HIP(ctx, hipEventSynchronize(p->ev1));
+    LP_HIP(ctx, hipGetLastError());
+    float ms = 0.f;
+    LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_status = status;
+    p->last_iters = p->h_state->iters;
+    if (stats) {
+        stats->status = status;
+        stats->pivots = p->h_state->iters;
+        stats->launches = launches;
+        stats->solve_ms = ms;
+        stats->update_ms = 0.f;
+        stats->update_launches = 0;
+        stats->bytes_per_pivot = 16.0 * (double)d.m * (double)(d.n + 1);
+    }
+    return status;
+}

@@ -32,9 +32,22 @@ struct SimplexDev {
     SimplexState* state;
 };
 
+// Look-ahead batch buffers (simplex_lookahead.hip).
+struct LookDev {
+    int J;          // pivots staged per batch
+    int rows_pad;   // row stride of etaL (m+1 rounded up to 8)
+    double* etaL;   // J x rows_pad: eta columns of F (:198-204); entry r = 1/u_r, entry m = cost row
+    double* etaP;   // J x ld: pivot rows before scaling (entry n = xB_r)
+    double* dvec;   // ld: current reduced-cost row (entry n = -objective)
+    double* rhs;    // rows_pad: current xB
+    int* piv;       // 2 x J: (entering column, leaving position) of each staged pivot
+    int* count;     // pivots staged by the last selector launch
+};
+
 struct lp_simplex_problem {
     lp_context* ctx = nullptr;
     SimplexDev dev{};
+    LookDev look{};
     int n_orig = 0;
     size_t tableau_bytes = 0;
     double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset
@@ -56,3 +69,9 @@ int lp_simplex_crash(lp_simplex_problem* p);
 int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
 int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, float* ms_out);
+
+// simplex_lookahead.hip
+int lp_lookahead_pick_j(int m, int n);
+int lp_lookahead_prepare(lp_simplex_problem* p);
+int lp_lookahead_init_vectors(lp_simplex_problem* p);
+int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);

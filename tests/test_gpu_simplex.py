@@ -10,6 +10,8 @@ from tests import lpcases
 
 pytestmark = pytest.mark.gpu
 
+ALGOS = [capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD]
+
 
 def _run(ctx, A, b, c, basis, maximize, n_orig, trace_cap=1 << 14, max_iter=capi.MAX_ITER,
          algo=capi.SIMPLEX_AUTO):
@@ -47,20 +49,22 @@ def test_known_answers(ctx):
 
 @pytest.mark.parametrize("seed,m,n", [(0, 2, 5), (1, 8, 16), (2, 16, 32), (3, 33, 71),
                                        (4, 64, 128), (5, 128, 256), (6, 100, 1500)])
-def test_random_lp_bit_exact(ctx, seed, m, n):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_random_lp_bit_exact(ctx, seed, m, n, algo):
     A, b, c, basis = lpcases.random_lp(seed, m, n)
     r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
-    g = _run(ctx, A, b, c, basis, True, n - m)
+    g = _run(ctx, A, b, c, basis, True, n - m, algo=algo)
     assert r["status"] == o.OPTIMAL and r["iters"] > 0
     _assert_bit_exact(g, r)
 
 
-def test_baseline_config_512x1024(ctx):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_baseline_config_512x1024(ctx, algo):
     """BASELINE.json configs[1]: m=512, n=1024, seed 0."""
     m, n = 512, 1024
     A, b, c, basis = lpcases.random_lp(0, m, n)
     r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
-    g = _run(ctx, A, b, c, basis, True, n - m)
+    g = _run(ctx, A, b, c, basis, True, n - m, algo=algo)
     _assert_bit_exact(g, r)
     # size-independent properties of the final tableau: basic columns are exact unit
     # vectors, reduced costs of an optimum are <= eps, xB >= 0 up to rounding
@@ -90,13 +94,14 @@ def test_against_reference_shaped_oracle(ctx, seed, m, n):
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
 @pytest.mark.parametrize("maximize", [True, False])
-def test_general_basis_crash_and_minimise(ctx, seed, maximize):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_general_basis_crash_and_minimise(ctx, seed, maximize, algo):
     """Non-slack initial basis (computeBFS, SimplexSolover.h:423) and the minimise rules
     (:163-174)."""
     A, b, c, basis = lpcases.general_lp(seed, 9, 20)
     n = A.shape[1]
     r = o.simplex_tableau(A, b, c, basis, maximize, n, trace_cap=4096, want_tableau=True)
-    g = _run(ctx, A, b, c, basis, maximize, n)
+    g = _run(ctx, A, b, c, basis, maximize, n, algo=algo)
     assert r["status"] == o.OPTIMAL
     _assert_bit_exact(g, r)
 
@@ -107,10 +112,15 @@ def test_status_codes(ctx):
     A = np.array([[4, 3, 0, 1], [0, 4, 0, 4.0]])   # main.cpp:24-34 (commented-out LP), basis {0,2}
     assert ctx.simplex_solve(A, [4, 6.0], [5, 1, 0, 0.0], [0, 2], False, 4)["status"] == capi.SINGULAR
     A, b, c, basis = lpcases.random_lp(5, 16, 32)
-    r = o.simplex_tableau(A, b, c, basis, True, 16, max_iter=3, trace_cap=8, want_tableau=True)
-    g = _run(ctx, A, b, c, basis, True, 16, max_iter=3)
-    assert g["status"] == capi.ITER_LIMIT
-    _assert_bit_exact(g, r)
+    for algo in ALGOS:
+        for lim in (1, 3, 16, 17):
+            r = o.simplex_tableau(A, b, c, basis, True, 16, max_iter=lim, trace_cap=64, want_tableau=True)
+            g = _run(ctx, A, b, c, basis, True, 16, max_iter=lim, algo=algo)
+            _assert_bit_exact(g, r)
+        A1 = np.array([[1.0, -1.0, 1.0]])
+        p = ctx.simplex_problem(A1, [1.0], [1.0, 1.0, 0.0], [2], True, 2)
+        assert p.run(algo=algo)[0] == capi.UNBOUNDED
+        p.free()
     with pytest.raises(capi.LPError):
         ctx.simplex_solve(A, b, c, [0] * 15 + [99], True, 16)
     with pytest.raises(capi.LPError):
@@ -125,8 +135,9 @@ def test_degenerate_ties(ctx):
     c = np.array([3, 2, 0, 0, 0.0])
     basis = np.array([2, 3, 4], dtype=np.int32)
     r = o.simplex_tableau(A, b, c, basis, True, 2, trace_cap=64, want_tableau=True)
-    g = _run(ctx, A, b, c, basis, True, 2)
-    _assert_bit_exact(g, r)
+    for algo in ALGOS:
+        g = _run(ctx, A, b, c, basis, True, 2, algo=algo)
+        _assert_bit_exact(g, r)
 
 
 def test_reset_and_repeat(ctx):
