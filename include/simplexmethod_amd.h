@@ -122,6 +122,11 @@ void lp_simplex_free(lp_simplex_problem* p);
 int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,
                           float* ms_per_launch_out);
 
+/* Diagnostic (not part of the drop-in surface): first call with cap_pivots > 0 turns the
+ * look-ahead selector's per-phase cycle stamps on; a later call copies 8 stamps per pivot
+ * (s_memtime ticks) for the first cap_pivots pivots of the last run into `out`.         */
+int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long long* out);
+
 /* Batched simplex (BASELINE.json configs[4]): `batch` independent LPs of one
  * shape, one LP per workgroup.  Arrays are concatenated per LP: A batch*m*n
  * (each column-major), b batch*m, c batch*n, basis_in batch*m; outputs x_out

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lp_simplex_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, C.c_int, _dp]),
     "lp_simplex_free": (None, [_vp]),
     "lp_bench_rank1_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp]),
+    "lp_debug_simplex_stamps": (C.c_int, [_vp, C.c_int, _u64p]),
     "lp_simplex_solve_batched": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _ip,
                                            C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
                                            _ip, _ip]),

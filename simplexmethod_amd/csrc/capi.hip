@@ -122,6 +122,7 @@ void lp_simplex_free(lp_simplex_problem* p) {
     (void)hipFree(p->dnonbasic0); (void)hipFree(p->dx);
     (void)hipFree(p->look.etaL); (void)hipFree(p->look.etaP); (void)hipFree(p->look.dvec);
     (void)hipFree(p->look.rhs); (void)hipFree(p->look.piv); (void)hipFree(p->look.count);
+    (void)hipFree(p->look.stamps);
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -336,6 +337,24 @@ int lp_simplex_solve(lp_context* ctx, const double* A, int m, int n, const doubl
     }
     lp_simplex_free(p);
     return rc;
+}
+
+// Diagnostic: switches the look-ahead selector's per-phase cycle stamps on (cap_pivots > 0)
+// and, after a run, copies them out: 8 stamps per pivot (s_memtime ticks).
+int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long long* out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p->look.stamps) {
+        if (cap_pivots <= 0) return LP_OPTIMAL;
+        LP_HIP(ctx, hipMalloc(&p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64)));
+        LP_HIP(ctx, hipMemset(p->look.stamps, 0, sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64)));
+        return LP_OPTIMAL;
+    }
+    if (out)
+        LP_HIP(ctx, hipMemcpy(out, p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)cap_pivots,
+                              hipMemcpyDeviceToHost));
+    return LP_OPTIMAL;
 }
 
 int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,

@@ -6,9 +6,17 @@
 // That is not an associative reduction, but it is a chain of "records": once
 // `best` holds v_p, the next accepted entry is the FIRST j > p with
 // v_j > v_p + eps, and no entry before p can qualify again (it was either
-// accepted with a smaller value or rejected against a smaller threshold).  One
-// wave therefore replays the scan exactly as a short sequence of jumps, each a
-// parallel "first index above threshold" (expected ~ln(len) jumps).
+// accepted with a smaller value or rejected against a smaller threshold).
+//
+// One wave replays the scan exactly:
+//   fast path  — let M be the maximum and jM its first index, P the maximum of the
+//     incoming `best` and of every entry before jM.  The scan's value v just before
+//     jM satisfies P - eps <= v <= P, so if M > P + eps the entry jM is accepted
+//     whatever v is, and nothing after it can be (all entries <= M): answer (M, jM)
+//     with three wave reductions.
+//   slow path  — (a near-tie, |M - P| <= eps, e.g. degenerate vertices) the chain is
+//     replayed jump by jump, each jump a parallel "first index above threshold".
+// Reductions use DPP row operations + row_bcast (gfx9 family), not ds_bpermute.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,28 +25,73 @@
 
 namespace lpdev {
 
+// ---- DPP wave reductions (result valid in every lane) -----------------------
+#define LP_DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define LP_DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define LP_DPP_ROW_HALF_MIRROR 0x141
+#define LP_DPP_ROW_MIRROR 0x140
+#define LP_DPP_ROW_BCAST15 0x142
+#define LP_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
+    int o;
+    o = dpp_i32<LP_DPP_QUAD_XOR1, 0xF>(v); v = o < v ? o : v;
+    o = dpp_i32<LP_DPP_QUAD_XOR2, 0xF>(v); v = o < v ? o : v;
+    o = dpp_i32<LP_DPP_ROW_HALF_MIRROR, 0xF>(v); v = o < v ? o : v;
+    o = dpp_i32<LP_DPP_ROW_MIRROR, 0xF>(v); v = o < v ? o : v;
+    o = dpp_i32<LP_DPP_ROW_BCAST15, 0xA>(v); v = o < v ? o : v;
+    o = dpp_i32<LP_DPP_ROW_BCAST31, 0xC>(v); v = o < v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <bool WANT_MAX>
+__device__ __forceinline__ double wave_ext_f64(double v) {
+    double o;
+#define LP_STEP(CTRL, MASK)                              \
+    o = dpp_f64<CTRL, MASK>(v);                          \
+    v = WANT_MAX ? (o > v ? o : v) : (o < v ? o : v);
+    LP_STEP(LP_DPP_QUAD_XOR1, 0xF)
+    LP_STEP(LP_DPP_QUAD_XOR2, 0xF)
+    LP_STEP(LP_DPP_ROW_HALF_MIRROR, 0xF)
+    LP_STEP(LP_DPP_ROW_MIRROR, 0xF)
+    LP_STEP(LP_DPP_ROW_BCAST15, 0xA)
+    LP_STEP(LP_DPP_ROW_BCAST31, 0xC)
+#undef LP_STEP
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 __device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
-    return __shfl(v, src_lane, 64);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src_lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // Exact replay of the sequential chain over `len` entries read through `load`
 // (load(j, ok) returns v_j and sets ok=false for ineligible j), executed by ONE
-// full wave (all 64 lanes must call).  Returns the selected index or -1; `best`
-// ends as the chain's final value (+-inf if nothing was eligible).
-// WANT_MAX: the :153-161 form (v > best + eps); otherwise the :164-172 / :181-192
-// form (v < best - eps).
+// full wave (all 64 lanes must call, with identical arguments).  Returns the
+// selected index or -1; `best` ends as the chain's final value (+-inf if nothing
+// was eligible).  WANT_MAX: the :153-161 form (v > best + eps); otherwise the
+// :164-172 / :181-192 form (v < best - eps).
 template <bool WANT_MAX, typename Load>
 __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
-    constexpr int K = 16;            // entries per lane per tile
+    constexpr int K = 16;  // entries per lane per tile
     constexpr int TILE = 64 * K;
     const int lane = threadIdx.x & 63;
     const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
@@ -46,14 +99,40 @@ __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
     int sel = -1;
     for (int base = 0; base < len; base += TILE) {
         double val[K];
+        double lext = sentinel;  // this lane's extreme value and its first index
+        int lidx = INT_MAX;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int j = base + k * 64 + lane;
+            // unconditional (clamped) load so that all K loads are in flight together
             bool ok = false;
-            double v = sentinel;
-            if (j < len) v = load(j, ok);
-            val[k] = ok ? v : sentinel;
+            double v = load(j < len ? j : len - 1, ok);
+            v = (ok && j < len) ? v : sentinel;
+            val[k] = v;
+            if (WANT_MAX ? (v > lext) : (v < lext)) {
+                lext = v;
+                lidx = j;
+            }
         }
+        // ---- fast path
+        const double M = wave_ext_f64<WANT_MAX>(lext);
+        const double thr_in = WANT_MAX ? best + eps : best - eps;
+        if (!(WANT_MAX ? (M > thr_in) : (M < thr_in))) continue;  // nothing here is accepted
+        const int jM = wave_min_i32((lext == M) ? lidx : INT_MAX);
+        double lp = sentinel;  // extreme of this lane's entries before jM
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = base + k * 64 + lane;
+            if (j < jM && (WANT_MAX ? (val[k] > lp) : (val[k] < lp))) lp = val[k];
+        }
+        double P = wave_ext_f64<WANT_MAX>(lp);
+        if (WANT_MAX ? (best > P) : (best < P)) P = best;
+        if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+            best = M;
+            sel = jM;
+            continue;
+        }
+        // ---- slow path: replay the chain jump by jump (near-ties within eps)
         for (;;) {
             const double thr = WANT_MAX ? best + eps : best - eps;
             int cand = INT_MAX;
@@ -73,6 +152,107 @@ __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
         }
     }
     return sel;
+}
+
+// ---------------------------------------------------------------------------
+// Workgroup-wide form of the same scan for values that already sit in LDS.
+// Every thread of the block must call it (it contains barriers).  Thread t owns
+// the KT = ceil(len/NT) consecutive entries [t*KT, t*KT+KT), so (wave, lane) order
+// is index order.  Stage 1: every wave reduces its slice to (M_w, first index j_w,
+// P_w = maximum of the wave's entries before j_w).  Stage 2: wave 0 combines the
+// <= 16 slices: global M, the first wave w* attaining it, P = max(M_w for w < w*,
+// P_w*).  If M > P + eps the answer is (M, j_w*) as in wave_chain_select's fast
+// path; otherwise wave 0 replays the whole chain (slow path).
+// ---------------------------------------------------------------------------
+struct BlockSelScratch {  // 16-B aligned, lives in LDS
+    double M[16];
+    double P[16];
+    int J[16];
+    double best;
+    int sel;
+    int pad;
+};
+
+template <bool WANT_MAX>
+__device__ __forceinline__ double ext2(double a, double b) {
+    return WANT_MAX ? (a > b ? a : b) : (a < b ? a : b);
+}
+
+template <bool WANT_MAX>
+__device__ int block_chain_select(const double* vals, const unsigned char* mask, int len,
+                                  double eps, double& best_out, BlockSelScratch* sc) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    const int KT = (len + nt - 1) / nt;
+    double lv = sentinel, lp = sentinel;  // thread extreme, extreme of its entries before it
+    int lj = INT_MAX;
+    for (int k = 0; k < KT; ++k) {
+        const int j = tid * KT + k;
+        const int jc = j < len ? j : len - 1;
+        double v = vals[jc];
+        const bool ok = (j < len) && (mask == nullptr || mask[jc] != 0);
+        v = ok ? v : sentinel;
+        if (WANT_MAX ? (v > lv) : (v < lv)) {
+            lp = lv;  // everything seen so far precedes the new extreme
+            lv = v;
+            lj = j;
+        } else {
+            // entries after the extreme do not matter for P
+        }
+    }
+    // stage 1: this wave's slice
+    const double Mw = wave_ext_f64<WANT_MAX>(lv);
+    const unsigned long long hit = __ballot(lv == Mw && lj != INT_MAX);
+    int L = hit ? (int)__builtin_ctzll(hit) : 0;
+    const int jw = hit ? __builtin_amdgcn_readlane(lj, L) : INT_MAX;
+    const double contrib = (lane < L) ? lv : ((lane == L) ? lp : sentinel);
+    const double Pw = wave_ext_f64<WANT_MAX>(hit ? contrib : sentinel);
+    if (lane == 0) {
+        sc->M[wave] = Mw;
+        sc->P[wave] = Pw;
+        sc->J[wave] = jw;
+    }
+    __syncthreads();
+    // stage 2: wave 0 combines the slices
+    if (wave == 0) {
+        const bool has = lane < nwaves;
+        const double Ml = has ? sc->M[lane] : sentinel;
+        const double Pl = has ? sc->P[lane] : sentinel;
+        const int Jl = has ? sc->J[lane] : INT_MAX;
+        const double M = wave_ext_f64<WANT_MAX>(Ml);
+        const unsigned long long whit = __ballot(has && Ml == M && Jl != INT_MAX);
+        int sel = -1;
+        double best = sentinel;
+        bool slow = false;
+        if (whit) {
+            const int W = (int)__builtin_ctzll(whit);
+            const int jM = __builtin_amdgcn_readlane(Jl, W);
+            const double Pin = wave_bcast_f64(Pl, W);
+            const double Pprev = wave_ext_f64<WANT_MAX>((lane < W) ? Ml : sentinel);
+            const double P = ext2<WANT_MAX>(Pprev, Pin);
+            if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+                best = M;
+                sel = jM;
+            } else {
+                slow = true;
+            }
+        }
+        if (slow) {
+            auto load = [&](int j, bool& ok) {
+                ok = (mask == nullptr) || mask[j] != 0;
+                return vals[j];
+            };
+            sel = wave_chain_select<WANT_MAX>(len, eps, best, load);
+        }
+        if (lane == 0) {
+            sc->best = best;
+            sc->sel = sel;
+        }
+    }
+    __syncthreads();
+    best_out = sc->best;
+    return sc->sel;
 }
 
 }  // namespace lpdev

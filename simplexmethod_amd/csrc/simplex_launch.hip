@@ -28,10 +28,11 @@ constexpr int kRunning = -100;  // SimplexState::status while pivoting
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_simplex_select(SimplexDev d) {
     SimplexState* st = d.state;
-    // all LDS in the dynamic region (keeps its base 16-B aligned): u[m+1], then 3 ints
+    // all LDS in the dynamic region (keeps its base 16-B aligned): u[m+1], ratio[m], 3 ints
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     double* s_u = s_dyn;
-    int* s_int = reinterpret_cast<int*>(s_dyn + (d.m + 2));
+    double* s_ratio = s_dyn + (d.m + 2);
+    int* s_int = reinterpret_cast<int*>(s_dyn + 2 * (d.m + 2));
     int& s_enter = s_int[0];
     int& s_leave = s_int[1];
     int& s_flag = s_int[2];
@@ -82,7 +83,10 @@ __global__ __launch_bounds__(1024) void k_simplex_select(SimplexDev d) {
     for (int i = tid; i <= m; i += blockDim.x) {
         const double ui = d.T[(size_t)i * ld + e];
         s_u[i] = ui;
-        if (i < m && !(ui <= eps)) any_pos = 1;  // (u.array() <= EPS).all(), :179
+        if (i < m) {
+            s_ratio[i] = (ui > eps) ? d.T[(size_t)i * ld + n] / ui : INFINITY;  // :185-186
+            if (!(ui <= eps)) any_pos = 1;  // (u.array() <= EPS).all(), :179
+        }
     }
     if (any_pos) s_flag = 1;
     __syncthreads();
@@ -96,9 +100,8 @@ __global__ __launch_bounds__(1024) void k_simplex_select(SimplexDev d) {
     if (tid < 64) {
         double theta;
         auto load = [&](int i, bool& ok) {
-            const double ui = s_u[i];
-            ok = ui > eps;                                            // :185
-            return ok ? d.T[(size_t)i * ld + n] / ui : 0.0;           // xB(i)/u(i), :186
+            ok = true;  // ineligible rows hold +inf, which the < scan never takes
+            return s_ratio[i];
         };
         const int r = lpdev::wave_chain_select<false>(m, eps, theta, load);  // :187-190
         if (tid == 0) s_leave = r;
@@ -340,7 +343,7 @@ int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_si
     lp_context* ctx = p->ctx;
     const SimplexDev& d = p->dev;
     hipStream_t s = ctx->stream;
-    const size_t shm = sizeof(double) * (size_t)(d.m + 2) + 16;
+    const size_t shm = 2 * sizeof(double) * (size_t)(d.m + 2) + 16;
     int launches = 0;
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_state_init, 1, 1, 0, s, d, eps, max_iter);

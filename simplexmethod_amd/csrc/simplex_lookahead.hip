@@ -28,43 +28,54 @@ constexpr int kRunning = -100;
 constexpr int SEL_THREADS = 1024;
 
 // LDS carve of the selector (all in the dynamic region, 16-B aligned pieces)
+struct QInfo {   // one staged pivot, read with a single 16-B LDS load
+    double inv;  // 1/u_r
+    int rq;      // leaving position
+    int eq;      // entering column
+};
+
+constexpr int kScratchDoubles = (int)(sizeof(lpdev::BlockSelScratch) / 8);
+
 struct SelLds {
+    lpdev::BlockSelScratch* sc;  // chain-select scratch (16-B aligned, first)
+    QInfo* qi;      // J   : staged pivots (16-B aligned)
     double* d;      // n+1 : reduced-cost row (entry n = -objective)
     double* rhs;    // m   : xB
     double* u;      // m   : entering column of the current tableau
+    double* ratio;  // m   : xB_i/u_i where u_i > eps, +inf elsewhere (:185-186)
     double* lcH;    // J x m     : staged eta columns (entry r = 1/u_r)
     double* prH;    // J x (n+1) : staged pivot rows (before scaling)
-    double* inv;    // J
     double* f64;    // 4 scalars: ur, inv, lm, rhs_r
-    int* rq;        // J : leaving positions
-    int* eq;        // J : entering columns
+    int* basis;     // m : N by position
     int* i32;       // 4 scalars: enter, leave
     unsigned char* nb;  // n : non-basic flags
 };
 
+__host__ __device__ inline size_t sel_lds_doubles(int m, int n, int J) {
+    return (size_t)kScratchDoubles + 2 * (size_t)J + (size_t)(n + 1) + 3 * (size_t)m +
+           (size_t)J * ((size_t)m + n + 1) + 4;
+}
+
 __host__ __device__ inline size_t sel_lds_bytes(int m, int n, int J) {
-    size_t dbl = (size_t)(n + 1) + 2 * (size_t)m + (size_t)J * ((size_t)m + n + 1) + J + 4;
-    dbl = (dbl + 1) & ~(size_t)1;
-    size_t bytes = dbl * 8 + (size_t)(2 * J + 4) * 4;
+    size_t bytes = sel_lds_doubles(m, n, J) * 8 + (size_t)(m + 4) * 4;
     bytes = (bytes + 15) & ~(size_t)15;
     return bytes + (size_t)n + 16;
 }
 
 __device__ inline SelLds carve(double* base, int m, int n, int J) {
     SelLds s;
-    s.d = base;
+    s.sc = reinterpret_cast<lpdev::BlockSelScratch*>(base);
+    s.qi = reinterpret_cast<QInfo*>(base + kScratchDoubles);
+    s.d = base + kScratchDoubles + 2 * (size_t)J;
     s.rhs = s.d + (n + 1);
     s.u = s.rhs + m;
-    s.lcH = s.u + m;
+    s.ratio = s.u + m;
+    s.lcH = s.ratio + m;
     s.prH = s.lcH + (size_t)J * m;
-    s.inv = s.prH + (size_t)J * (n + 1);
-    s.f64 = s.inv + J;
-    size_t dbl = (size_t)(n + 1) + 2 * (size_t)m + (size_t)J * ((size_t)m + n + 1) + J + 4;
-    dbl = (dbl + 1) & ~(size_t)1;
-    s.rq = reinterpret_cast<int*>(base + dbl);
-    s.eq = s.rq + J;
-    s.i32 = s.eq + J;
-    size_t bytes = dbl * 8 + (size_t)(2 * J + 4) * 4;
+    s.f64 = s.prH + (size_t)J * (n + 1);
+    s.basis = reinterpret_cast<int*>(base + sel_lds_doubles(m, n, J));
+    s.i32 = s.basis + m;
+    size_t bytes = sel_lds_doubles(m, n, J) * 8 + (size_t)(m + 4) * 4;
     bytes = (bytes + 15) & ~(size_t)15;
     s.nb = reinterpret_cast<unsigned char*>(base) + bytes;
     return s;
@@ -85,12 +96,20 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
     int iters = st->iters;
     for (int j = tid; j <= n; j += SEL_THREADS) s.d[j] = la.dvec[j];
     for (int j = tid; j < n; j += SEL_THREADS) s.nb[j] = d.nonbasic[j];
-    for (int i = tid; i < m; i += SEL_THREADS) s.rhs[i] = la.rhs[i];
+    for (int i = tid; i < m; i += SEL_THREADS) {
+        s.rhs[i] = la.rhs[i];
+        s.basis[i] = d.basis[i];
+    }
     __syncthreads();
 
     int cnt = 0;
     int status = kRunning;
     const double* T = d.T;
+    unsigned long long* stamps = la.stamps ? la.stamps + (size_t)iters * 8 : nullptr;
+#define LP_STAMP(k)                                                                       \
+    do {                                                                                  \
+        if (stamps && tid == 0) stamps[(size_t)cnt * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
     for (int q0 = 0; q0 < J; ++q0) {
         const int sidx = q0;  // index of the pivot being staged
         if (iters >= max_iter) {  // SimplexSolover.h:429,:450
@@ -98,22 +117,18 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
             break;
         }
         // ---- pricing, :152-174, on the LDS-resident reduced-cost row
-        if (tid < 64) {
+        LP_STAMP(0);
+        int e;
+        {
             double best;
-            int e;
-            auto load = [&](int j, bool& ok) {
-                ok = s.nb[j] != 0;
-                return s.d[j];
-            };
             if (d.maximize)
-                e = lpdev::wave_chain_select<true>(n, eps, best, load);
+                e = lpdev::block_chain_select<true>(s.d, s.nb, n, eps, best, s.sc);
             else
-                e = lpdev::wave_chain_select<false>(n, eps, best, load);
+                e = lpdev::block_chain_select<false>(s.d, s.nb, n, eps, best, s.sc);
             const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
-            if (tid == 0) s.i32[0] = optimal ? -1 : e;
+            if (optimal) e = -1;
         }
-        __syncthreads();
-        const int e = s.i32[0];
+        LP_STAMP(1);
         if (e < 0) {
             status = LP_OPTIMAL;
             break;
@@ -122,66 +137,56 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         int any_pos = 0;
         for (int i = tid; i < m; i += SEL_THREADS) {
             double t = T[(size_t)i * ld + e];
+#pragma unroll 4
             for (int q = 0; q < sidx; ++q) {
-                const int rq = s.rq[q];
-                if (i == rq)
-                    t = t * s.inv[q];
-                else
-                    t = fma(s.lcH[(size_t)q * m + i], s.prH[(size_t)q * (n + 1) + e], t);
-                if (e == s.eq[q]) t = (i == rq) ? 1.0 : 0.0;
+                const QInfo qi = s.qi[q];
+                const double l = s.lcH[(size_t)q * m + i];
+                const double pe = s.prH[(size_t)q * (n + 1) + e];
+                t = (i == qi.rq) ? t * qi.inv : fma(l, pe, t);
+                if (e == qi.eq) t = (i == qi.rq) ? 1.0 : 0.0;
             }
             s.u[i] = t;
+            s.ratio[i] = (t > eps) ? s.rhs[i] / t : INFINITY;  // :185-186
             if (!(t <= eps)) any_pos = 1;  // :179
         }
         if (!__syncthreads_or(any_pos)) {
             status = LP_UNBOUNDED;
             break;
         }
+        LP_STAMP(2);
         // ---- ratio test, :181-194
-        if (tid < 64) {
-            double theta;
-            auto load = [&](int i, bool& ok) {
-                const double ui = s.u[i];
-                ok = ui > eps;
-                return ok ? s.rhs[i] / ui : 0.0;
-            };
-            const int r = lpdev::wave_chain_select<false>(m, eps, theta, load);
-            if (tid == 0) {
-                s.i32[1] = r;
-                if (r >= 0) {
-                    const double ur = s.u[r];
-                    s.f64[0] = ur;
-                    s.f64[1] = 1.0 / ur;        // F(r,r), :204
-                    s.f64[2] = -s.d[e] / ur;    // F row of the reduced costs
-                    s.f64[3] = s.rhs[r];
-                }
-            }
-        }
-        __syncthreads();
-        const int r = s.i32[1];
+        double theta;
+        // ineligible rows hold +inf, which the < scan never takes
+        const int r = lpdev::block_chain_select<false>(s.ratio, nullptr, m, eps, theta, s.sc);
+        LP_STAMP(3);
         if (r < 0) {
             status = LP_UNBOUNDED;
             break;
         }
-        const double ur = s.f64[0], inv = s.f64[1], lm = s.f64[2], rhs_r = s.f64[3];
+        const double ur = s.u[r];
+        const double inv = 1.0 / ur;       // F(r,r), :204
+        const double lm = -s.d[e] / ur;    // F row of the reduced costs
+        const double rhs_r = s.rhs[r];
+        __syncthreads();                   // everyone has read d[e], rhs[r] before they change
         // ---- pivot row of the CURRENT tableau (before scaling) + reduced-cost update
         double* prS = s.prH + (size_t)sidx * (n + 1);
         double* etaP = la.etaP + (size_t)sidx * ld;
         for (int j = tid; j < n; j += SEL_THREADS) {
             double t = T[(size_t)r * ld + j];
+#pragma unroll 4
             for (int q = 0; q < sidx; ++q) {
-                const int rq = s.rq[q];
-                if (r == rq)
-                    t = t * s.inv[q];
-                else
-                    t = fma(s.lcH[(size_t)q * m + r], s.prH[(size_t)q * (n + 1) + j], t);
-                if (j == s.eq[q]) t = (r == rq) ? 1.0 : 0.0;
+                const QInfo qi = s.qi[q];
+                const double l = s.lcH[(size_t)q * m + r];
+                const double pj = s.prH[(size_t)q * (n + 1) + j];
+                t = (r == qi.rq) ? t * qi.inv : fma(l, pj, t);
+                if (j == qi.eq) t = (r == qi.rq) ? 1.0 : 0.0;
             }
             prS[j] = t;
             etaP[j] = t;
             const double dj = fma(lm, t, s.d[j]);
             s.d[j] = (j == e) ? 0.0 : dj;
         }
+        LP_STAMP(4);
         // ---- eta column (:198-204) + xB update
         double* lcS = s.lcH + (size_t)sidx * m;
         double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
@@ -191,18 +196,21 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
             etaL[i] = l;
             s.rhs[i] = (i == r) ? rhs_r * inv : fma(l, rhs_r, s.rhs[i]);
         }
+        LP_STAMP(5);
         if (tid == 0) {
             prS[n] = rhs_r;
             etaP[n] = rhs_r;
             s.d[n] = fma(lm, rhs_r, s.d[n]);
             etaL[m] = lm;
-            s.rq[sidx] = r;
-            s.eq[sidx] = e;
-            s.inv[sidx] = inv;
+            QInfo qi;
+            qi.inv = inv;
+            qi.rq = r;
+            qi.eq = e;
+            s.qi[sidx] = qi;
             la.piv[2 * sidx] = e;
             la.piv[2 * sidx + 1] = r;
-            const int old = d.basis[r];
-            d.basis[r] = e;  // :196
+            const int old = s.basis[r];
+            s.basis[r] = e;  // :196
             s.nb[e] = 0;
             s.nb[old] = 1;
             if (iters < d.trace_cap) {
@@ -210,14 +218,20 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
                 d.trace_leave[iters] = r;
             }
         }
+        LP_STAMP(6);
+        __syncthreads();
+        LP_STAMP(7);
         ++iters;
         ++cnt;
-        __syncthreads();
     }
+#undef LP_STAMP
     __syncthreads();
     for (int j = tid; j <= n; j += SEL_THREADS) la.dvec[j] = s.d[j];
     for (int j = tid; j < n; j += SEL_THREADS) d.nonbasic[j] = s.nb[j];
-    for (int i = tid; i < m; i += SEL_THREADS) la.rhs[i] = s.rhs[i];
+    for (int i = tid; i < m; i += SEL_THREADS) {
+        la.rhs[i] = s.rhs[i];
+        d.basis[i] = s.basis[i];
+    }
     if (tid == 0) {
         *la.count = cnt;
         st->iters = iters;

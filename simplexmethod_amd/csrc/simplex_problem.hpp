@@ -42,6 +42,7 @@ struct LookDev {
     double* rhs;    // rows_pad: current xB
     int* piv;       // 2 x J: (entering column, leaving position) of each staged pivot
     int* count;     // pivots staged by the last selector launch
+    unsigned long long* stamps;  // diagnostic: 8 s_memtime stamps per pivot (nullptr = off)
 };
 
 struct lp_simplex_problem {
