@@ -1,0 +1,347 @@
+// batched_simplex.hip — many independent LPs of one shape, ONE LP PER WORKGROUP
+// (BASELINE.json configs[4]: 4096 LPs, m=128, n=256).
+//
+// Each workgroup runs the whole of Solver::solveWithBasis
+// (/root/reference/src/SimplexSolover.h:408-451) for its LP with the tableau resident in
+// LDS for the entire solve: HBM is touched once to load [A | b | c] and once to store the
+// vertex.  The tableau is kept in CONDENSED form — only the n-m non-basic columns, xB and
+// the reduced-cost row ((m+1) x (n-m+1) doubles; 133 KB at 128x256, which is why one LP
+// fills one CU's 160 KB LDS).  A pivot overwrites the entering column's slot with the
+// column of the variable that leaves (the eta column itself: fma(l_i, 1, 0) = l_i), so
+// every stored element has exactly the bits the full-tableau update
+// (oracle/lp_oracle.c: tableau_pivot) would give it.
+//
+// Slots are in arbitrary variable order after the first pivot, so the order-dependent
+// scans of SimplexSolover.h:153-161 / :181-192 are done on (value, key) pairs
+// (key = variable index for pricing, basis position for the ratio test):
+//   M  = extreme value, jM = smallest key attaining it, P = extreme over keys < jM;
+//   M beyond P by more than eps  =>  the sequential scan ends on jM (see
+//   device_select.hpp); otherwise the scan is replayed jump by jump.
+#include <cfloat>
+
+#include "device_select.hpp"
+#include "lp_internal.hpp"
+#include "batched_problem.hpp"
+
+namespace {
+
+constexpr int kRunning = -100;
+
+struct RedScratch {  // two alternating sets: a thread can be at most one reduction ahead
+    double v[2][16];
+    int a[2][16];
+    int b[2][16];
+};
+
+struct Red {
+    RedScratch* sc;
+    int phase;
+    int lane, wave, nwaves;
+};
+
+// Block-wide extreme of lv; ties -> smallest key; payload slot.  Every thread calls.
+template <bool WANT_MAX>
+__device__ __forceinline__ void block_argext(Red& R, double lv, int lkey, int lslot, double& M,
+                                             int& key, int& slot) {
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    const double Mw = lpdev::wave_ext_f64<WANT_MAX>(lv);
+    const int kw = lpdev::wave_min_i32((lv == Mw && lv != sentinel) ? lkey : INT_MAX);
+    const unsigned long long hit = __ballot(lv == Mw && lkey == kw && kw != INT_MAX);
+    const int sw = hit ? __builtin_amdgcn_readlane(lslot, (int)__builtin_ctzll(hit)) : -1;
+    const int ph = R.phase;
+    R.phase ^= 1;
+    if (R.lane == 0) {
+        R.sc->v[ph][R.wave] = Mw;
+        R.sc->a[ph][R.wave] = kw;
+        R.sc->b[ph][R.wave] = sw;
+    }
+    __syncthreads();
+    M = sentinel;
+    key = INT_MAX;
+    slot = -1;
+    for (int w = 0; w < R.nwaves; ++w) {
+        const double v = R.sc->v[ph][w];
+        const int k = R.sc->a[ph][w];
+        const bool better = WANT_MAX ? (v > M) : (v < M);
+        if (k != INT_MAX && (better || (v == M && k < key))) {
+            M = v;
+            key = k;
+            slot = R.sc->b[ph][w];
+        }
+    }
+}
+
+template <bool WANT_MAX>
+__device__ __forceinline__ double block_ext(Red& R, double lv) {
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    const double Mw = lpdev::wave_ext_f64<WANT_MAX>(lv);
+    const int ph = R.phase;
+    R.phase ^= 1;
+    if (R.lane == 0) R.sc->v[ph][R.wave] = Mw;
+    __syncthreads();
+    double M = sentinel;
+    for (int w = 0; w < R.nwaves; ++w) M = lpdev::ext2<WANT_MAX>(M, R.sc->v[ph][w]);
+    return M;
+}
+
+// Block-wide minimum key with its value and slot (slow path jumps).
+__device__ __forceinline__ void block_minkey(Red& R, int lkey, double lval, int lslot, int& key,
+                                             double& val, int& slot) {
+    const int kw = lpdev::wave_min_i32(lkey);
+    const unsigned long long hit = __ballot(lkey == kw && kw != INT_MAX);
+    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+    const double vw = lpdev::wave_bcast_f64(lval, src);
+    const int sw = __builtin_amdgcn_readlane(lslot, src);
+    const int ph = R.phase;
+    R.phase ^= 1;
+    if (R.lane == 0) {
+        R.sc->v[ph][R.wave] = vw;
+        R.sc->a[ph][R.wave] = kw;
+        R.sc->b[ph][R.wave] = sw;
+    }
+    __syncthreads();
+    key = INT_MAX;
+    val = 0.0;
+    slot = -1;
+    for (int w = 0; w < R.nwaves; ++w) {
+        const int k = R.sc->a[ph][w];
+        if (k < key) {
+            key = k;
+            val = R.sc->v[ph][w];
+            slot = R.sc->b[ph][w];
+        }
+    }
+}
+
+// The sequential EPS-hysteresis scan (SimplexSolover.h:153-161 / :164-172 / :181-192)
+// over `count` (value, key) entries stored in arbitrary order; entry s is read through
+// get(s, value, key, eligible).  Every thread of the block calls.  Returns the slot of the
+// selected entry (-1 if none) and the scan's final value in `best`.
+template <bool WANT_MAX, typename Get>
+__device__ int block_scan_keyed(Red& R, int count, double eps, double& best, Get get) {
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double lv = sentinel;
+    int lkey = INT_MAX, lslot = -1;
+    for (int s = tid; s < count; s += nt) {
+        double v;
+        int k;
+        bool ok;
+        get(s, v, k, ok);
+        if (ok && ((WANT_MAX ? (v > lv) : (v < lv)) || (v == lv && k < lkey))) {
+            lv = v;
+            lkey = k;
+            lslot = s;
+        }
+    }
+    double M;
+    int jM, sM;
+    block_argext<WANT_MAX>(R, lv, lkey, lslot, M, jM, sM);
+    best = sentinel;
+    if (sM < 0) return -1;
+    double lp = sentinel;
+    for (int s = tid; s < count; s += nt) {
+        double v;
+        int k;
+        bool ok;
+        get(s, v, k, ok);
+        if (ok && k < jM) lp = lpdev::ext2<WANT_MAX>(lp, v);
+    }
+    const double P = block_ext<WANT_MAX>(R, lp);
+    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+        best = M;
+        return sM;
+    }
+    // near-tie: replay the chain.  The next accepted entry is the one of smallest key among
+    // those beyond the threshold (entries before the current one cannot qualify again).
+    int sel = -1;
+    for (;;) {
+        const double thr = WANT_MAX ? best + eps : best - eps;
+        int ck = INT_MAX, cs = -1;
+        double cv = 0.0;
+        for (int s = tid; s < count; s += nt) {
+            double v;
+            int k;
+            bool ok;
+            get(s, v, k, ok);
+            if (ok && (WANT_MAX ? (v > thr) : (v < thr)) && k < ck) {
+                ck = k;
+                cv = v;
+                cs = s;
+            }
+        }
+        int key, slot;
+        double val;
+        block_minkey(R, ck, cv, cs, key, val, slot);
+        if (slot < 0) break;
+        best = val;
+        sel = slot;
+    }
+    return sel;
+}
+
+__global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = d.m, n = d.n, nn = n - m, W = nn + 1, pitch = d.pitch;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lp = blockIdx.x;
+    // ---- LDS carve
+    RedScratch* rs = reinterpret_cast<RedScratch*>(smem);
+    double* T = smem + sizeof(RedScratch) / 8;        // (m+1) x pitch
+    double* prow = T + (size_t)(m + 1) * pitch;       // W
+    double* lcol = prow + W;                          // m+1
+    double* ratio = lcol + (m + 1);                   // m
+    int* slotvar = reinterpret_cast<int*>(ratio + m); // nn : variable held by each slot
+    int* basis = slotvar + nn;                        // m  : N by position
+    int* posofvar = basis + m;                        // n  : scratch for the initial split
+    Red R{rs, 0, tid & 63, tid >> 6, nt >> 6};
+
+    const double* A = d.A + (size_t)lp * m * n;
+    const double* b = d.b + (size_t)lp * m;
+    const double* c = d.c + (size_t)lp * n;
+    const int* bin = d.basis_in + (size_t)lp * m;
+
+    // ---- initial condensed tableau for the slack identity basis (Symmetrical.cpp:169-188)
+    for (int j = tid; j < n; j += nt) posofvar[j] = -1;
+    __syncthreads();
+    for (int t = tid; t < m; t += nt) {
+        basis[t] = bin[t];
+        posofvar[bin[t]] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {  // slots take the non-basic variables in ascending order
+        int s = 0;
+        for (int j = 0; j < n; ++j)
+            if (posofvar[j] < 0) slotvar[s++] = j;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nn * m; idx += nt) {
+        const int s = idx / m, i = idx - s * m;
+        T[(size_t)i * pitch + s] = A[(size_t)slotvar[s] * m + i];
+    }
+    for (int i = tid; i < m; i += nt) T[(size_t)i * pitch + nn] = b[i];
+    for (int s = tid; s < nn; s += nt) T[(size_t)m * pitch + s] = c[slotvar[s]];
+    if (tid == 0) T[(size_t)m * pitch + nn] = 0.0;
+    __syncthreads();
+
+    const double eps = d.eps;
+    int iters = 0;
+    int status = kRunning;
+    // flattened (row, column) walk of the tableau: element idx = i*W + j
+    const int step_i = nt / W, step_j = nt - step_i * W;
+    const int i0 = tid / W, j0 = tid - i0 * W;
+    const int total = (m + 1) * W;
+
+    while (true) {
+        if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
+            status = LP_ITER_LIMIT;
+            break;
+        }
+        // ---- pricing over the non-basic slots, keyed by variable index (:152-174)
+        double best;
+        const double* drow = T + (size_t)m * pitch;
+        auto getd = [&](int s, double& v, int& k, bool& ok) {
+            v = drow[s];
+            k = slotvar[s];
+            ok = true;
+        };
+        const int se = d.maximize ? block_scan_keyed<true>(R, nn, eps, best, getd)
+                                  : block_scan_keyed<false>(R, nn, eps, best, getd);
+        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
+        if (optimal || se < 0) {
+            status = LP_OPTIMAL;
+            break;
+        }
+        // ---- entering column, unbounded test (:176-179), ratios (:185-186)
+        int any_pos = 0;
+        for (int i = tid; i < m; i += nt) {
+            const double ui = T[(size_t)i * pitch + se];
+            ratio[i] = (ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
+            if (!(ui <= eps)) any_pos = 1;
+        }
+        if (!__syncthreads_or(any_pos)) {
+            status = LP_UNBOUNDED;
+            break;
+        }
+        // ---- ratio test keyed by basis position (:181-194); +inf entries are never taken
+        double theta;
+        auto getr = [&](int i, double& v, int& k, bool& ok) {
+            v = ratio[i];
+            k = i;
+            ok = true;
+        };
+        const int r = block_scan_keyed<false>(R, m, eps, theta, getr);
+        if (r < 0) {
+            status = LP_UNBOUNDED;
+            break;
+        }
+        // ---- eta column (:198-204) and a copy of the pivot row
+        const double ur = T[(size_t)r * pitch + se];
+        const double inv = 1.0 / ur;
+        for (int j = tid; j < W; j += nt) prow[j] = T[(size_t)r * pitch + j];
+        for (int i = tid; i <= m; i += nt)
+            lcol[i] = (i == r) ? inv : -T[(size_t)i * pitch + se] / ur;
+        __syncthreads();
+        // ---- rank-1 update of every stored element; slot se receives the leaving column
+        {
+            int i = i0, j = j0;
+            for (int idx = tid; idx < total; idx += nt) {
+                double* p = T + (size_t)i * pitch + j;
+                const double l = lcol[i];
+                double t;
+                if (j == se)
+                    t = l;
+                else if (i == r)
+                    t = prow[j] * l;
+                else
+                    t = fma(l, prow[j], *p);
+                *p = t;
+                i += step_i;
+                j += step_j;
+                if (j >= W) {
+                    j -= W;
+                    ++i;
+                }
+            }
+        }
+        if (tid == 0) {
+            const int ve = slotvar[se];
+            slotvar[se] = basis[r];
+            basis[r] = ve;  // N(leave_pos) = enter, :196
+        }
+        ++iters;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- outputs: x(N(t)) = xB(t), zeros elsewhere (:131-132); basis; counters
+    double* x = d.x + (size_t)lp * n;
+    for (int j = tid; j < n; j += nt) x[j] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < m; t += nt) {
+        x[basis[t]] = T[(size_t)t * pitch + nn];
+        d.basis_out[(size_t)lp * m + t] = basis[t];
+    }
+    if (tid == 0) {
+        d.iters[lp] = iters;
+        d.status[lp] = status;
+    }
+}
+
+}  // namespace
+
+size_t lp_batched_lds_bytes(int m, int n, int* pitch_out) {
+    const int nn = n - m, W = nn + 1;
+    const int pitch = (W & 1) ? W : W + 1;  // odd pitch: conflict-free column reads
+    if (pitch_out) *pitch_out = pitch;
+    size_t dbl = sizeof(RedScratch) / 8 + (size_t)(m + 1) * pitch + W + (m + 1) + m;
+    size_t bytes = dbl * 8 + sizeof(int) * (size_t)(nn + m + n);
+    return (bytes + 15) & ~(size_t)15;
+}
+
+int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
+    const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);
+    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_batched_simplex, d.batch, 512, shm, ctx->stream, d);
+    return LP_OPTIMAL;
+}

@@ -2,6 +2,7 @@
 // mirror the reference's constructors, uploads/downloads, and dispatch to the kernels.
 #include <cmath>
 
+#include "batched_problem.hpp"
 #include "enum_problem.hpp"
 #include "lp_internal.hpp"
 #include "simplex_problem.hpp"
@@ -536,19 +537,33 @@ int lp_enum_solve(lp_context* ctx, const double* A, int m, int n, const double* 
 }
 
 // ===========================================================================
-// batched simplex — first version: LPs solved one after another on the device
+// batched simplex — one LP per workgroup (batched_simplex.hip).  LPs whose initial
+// basis is not the slack identity, or whose condensed tableau does not fit one CU's
+// LDS, go through the single-LP path one after another instead.
 // ===========================================================================
 
 struct lp_batched_problem {
     lp_context* ctx = nullptr;
     int batch = 0, m = 0, n = 0, n_orig = 0;
-    std::vector<lp_simplex_problem*> lps;
+    bool resident = false;              // true: LDS-resident kernel; false: per-LP fallback
+    BatchedDev dev{};
+    double *dA = nullptr, *db = nullptr, *dc = nullptr, *dx = nullptr;
+    int *dbasis_in = nullptr, *dbasis_out = nullptr, *diters = nullptr, *dstatus = nullptr;
+    std::vector<double> h_c;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<lp_simplex_problem*> lps;  // fallback
     std::vector<int> status, iters;
 };
 
 void lp_batched_free(lp_batched_problem* p) {
     if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
     for (auto* q : p->lps) lp_simplex_free(q);
+    (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dx);
+    (void)hipFree(p->dbasis_in); (void)hipFree(p->dbasis_out); (void)hipFree(p->diters);
+    (void)hipFree(p->dstatus);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
 }
 
@@ -558,6 +573,13 @@ int lp_batched_upload(lp_context* ctx, int batch, const double* A, int m, int n,
     if (!ctx || !problem_out) return LP_BAD_ARG;
     *problem_out = nullptr;
     if (batch <= 0) LP_FAIL(ctx, LP_BAD_ARG, "batch must be positive");
+    for (int k = 0; k < batch; ++k) {
+        int rc = check_canonical(ctx, A ? A + (size_t)k * m * n : nullptr, m, n,
+                                 b ? b + (size_t)k * m : nullptr, c ? c + (size_t)k * n : nullptr,
+                                 basis_in ? basis_in + (size_t)k * m : nullptr, n_orig);
+        if (rc) return rc;
+    }
+    LP_HIP(ctx, hipSetDevice(ctx->device));
     lp_batched_problem* p = new lp_batched_problem();
     p->ctx = ctx;
     p->batch = batch;
@@ -566,22 +588,101 @@ int lp_batched_upload(lp_context* ctx, int batch, const double* A, int m, int n,
     p->n_orig = n_orig;
     p->status.assign((size_t)batch, -100);
     p->iters.assign((size_t)batch, 0);
-    for (int k = 0; k < batch; ++k) {
-        lp_simplex_problem* q = nullptr;
-        int rc = lp_simplex_upload(ctx, A + (size_t)k * m * n, m, n, b + (size_t)k * m,
-                                   c + (size_t)k * n, basis_in + (size_t)k * m, maximize, n_orig, &q);
-        if (rc) {
-            lp_batched_free(p);
-            return rc;
+    p->h_c.assign(c, c + (size_t)batch * n);
+    // resident path needs: slack identity basis with zero basic costs in every LP, n > m,
+    // and the condensed tableau within one CU's LDS
+    bool identity = n > m;
+    for (int k = 0; k < batch && identity; ++k) {
+        const double* Ak = A + (size_t)k * m * n;
+        const double* ck = c + (size_t)k * n;
+        const int* bk = basis_in + (size_t)k * m;
+        for (int t = 0; t < m && identity; ++t) {
+            if (ck[bk[t]] != 0.0) identity = false;
+            for (int i = 0; i < m && identity; ++i)
+                if (Ak[(size_t)bk[t] * m + i] != ((i == t) ? 1.0 : 0.0)) identity = false;
         }
-        p->lps.push_back(q);
     }
+    int pitch = 0;
+    const size_t lds = lp_batched_lds_bytes(m, n, &pitch);
+    p->resident = identity && lds <= 160 * 1024;
+    if (!p->resident) {
+        for (int k = 0; k < batch; ++k) {
+            lp_simplex_problem* q = nullptr;
+            int rc = lp_simplex_upload(ctx, A + (size_t)k * m * n, m, n, b + (size_t)k * m,
+                                       c + (size_t)k * n, basis_in + (size_t)k * m, maximize,
+                                       n_orig, &q);
+            if (rc) {
+                lp_batched_free(p);
+                return rc;
+            }
+            p->lps.push_back(q);
+        }
+        *problem_out = p;
+        return LP_OPTIMAL;
+    }
+#define LP_TRY(expr)                        \
+    do {                                    \
+        hipError_t _e = (expr);             \
+        if (_e != hipSuccess) {             \
+            ctx->last_error = #expr;        \
+            lp_batched_free(p);             \
+            return -(int)_e;                \
+        }                                   \
+    } while (0)
+    hipStream_t s = ctx->stream;
+    const size_t B = (size_t)batch;
+    LP_TRY(hipMalloc(&p->dA, sizeof(double) * B * m * n));
+    LP_TRY(hipMalloc(&p->db, sizeof(double) * B * m));
+    LP_TRY(hipMalloc(&p->dc, sizeof(double) * B * n));
+    LP_TRY(hipMalloc(&p->dx, sizeof(double) * B * n));
+    LP_TRY(hipMalloc(&p->dbasis_in, sizeof(int) * B * m));
+    LP_TRY(hipMalloc(&p->dbasis_out, sizeof(int) * B * m));
+    LP_TRY(hipMalloc(&p->diters, sizeof(int) * B));
+    LP_TRY(hipMalloc(&p->dstatus, sizeof(int) * B));
+    LP_TRY(hipEventCreate(&p->ev0));
+    LP_TRY(hipEventCreate(&p->ev1));
+    LP_TRY(hipMemcpyAsync(p->dA, A, sizeof(double) * B * m * n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->db, b, sizeof(double) * B * m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * B * n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(p->dbasis_in, basis_in, sizeof(int) * B * m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipStreamSynchronize(s));
+#undef LP_TRY
+    BatchedDev& d = p->dev;
+    d.batch = batch;
+    d.m = m;
+    d.n = n;
+    d.pitch = pitch;
+    d.maximize = maximize ? 1 : 0;
+    d.A = p->dA;
+    d.b = p->db;
+    d.c = p->dc;
+    d.basis_in = p->dbasis_in;
+    d.x = p->dx;
+    d.basis_out = p->dbasis_out;
+    d.iters = p->diters;
+    d.status = p->dstatus;
     *problem_out = p;
     return LP_OPTIMAL;
 }
 
 int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_out) {
     if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    if (p->resident) {
+        p->dev.eps = eps;
+        p->dev.max_iter = max_iter;
+        LP_HIP(ctx, hipEventRecord(p->ev0, ctx->stream));
+        int rc = lp_batched_launch(ctx, p->dev);
+        if (rc) return rc;
+        LP_HIP(ctx, hipEventRecord(p->ev1, ctx->stream));
+        LP_HIP(ctx, hipEventSynchronize(p->ev1));
+        LP_HIP(ctx, hipGetLastError());
+        float ms = 0.f;
+        LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        if (ms_out) *ms_out = ms;
+        return LP_OPTIMAL;
+    }
     float total = 0.f;
     for (int k = 0; k < p->batch; ++k) {
         lp_simplex_stats st;
@@ -600,6 +701,34 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
 int lp_batched_download(lp_batched_problem* p, double* x_out, int* basis_out, double* obj_out,
                         int* iters_out, int* status_out) {
     if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    if (p->resident) {
+        const size_t B = (size_t)p->batch;
+        std::vector<double> x(B * p->n);
+        hipStream_t s = ctx->stream;
+        LP_HIP(ctx, hipMemcpyAsync(x.data(), p->dx, sizeof(double) * B * p->n, hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipMemcpyAsync(p->status.data(), p->dstatus, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipMemcpyAsync(p->iters.data(), p->diters, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+        if (basis_out)
+            LP_HIP(ctx, hipMemcpyAsync(basis_out, p->dbasis_out, sizeof(int) * B * p->m, hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipStreamSynchronize(s));
+        for (int k = 0; k < p->batch; ++k) {
+            const bool ok = p->status[(size_t)k] == LP_OPTIMAL;
+            const double* xk = x.data() + (size_t)k * p->n;
+            if (x_out && ok)  // x.head(n_orig), SimplexSolover.h:435-438
+                for (int j = 0; j < p->n_orig; ++j) x_out[(size_t)k * p->n_orig + j] = xk[j];
+            if (obj_out && ok) {  // Canonical::Evaluate, Canonical.cpp:86
+                double z = 0.0;
+                const double* ck = p->h_c.data() + (size_t)k * p->n;
+                for (int j = 0; j < p->n; ++j) z += ck[j] * xk[j];
+                obj_out[k] = z;
+            }
+            if (iters_out) iters_out[k] = p->iters[(size_t)k];
+            if (status_out) status_out[k] = p->status[(size_t)k];
+        }
+        return LP_OPTIMAL;
+    }
     for (int k = 0; k < p->batch; ++k) {
         const bool ok = p->status[(size_t)k] == LP_OPTIMAL;
         int rc = lp_simplex_download(p->lps[(size_t)k],

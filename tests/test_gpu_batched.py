@@ -1,0 +1,84 @@
+"""GPU parity: batched simplex (one LP per workgroup, BASELINE.json configs[4]) against the
+oracle's tableau restatement, LP by LP, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as o
+from simplexmethod_amd import capi
+from tests import lpcases
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seeds, m, n):
+    As, bs, cs, bas = zip(*[lpcases.random_lp(s, m, n) for s in seeds])
+    return np.stack(As), np.stack(bs), np.stack(cs), np.stack(bas)
+
+
+def _check(g, A, b, c, basis, maximize, n_orig, max_iter=capi.MAX_ITER):
+    for k in range(A.shape[0]):
+        r = o.simplex_tableau(A[k], b[k], c[k], basis[k], maximize, n_orig, max_iter=max_iter)
+        assert g["status"][k] == r["status"], k
+        assert g["iters"][k] == r["iters"], k
+        assert np.array_equal(g["basis"][k], r["basis"]), k
+        if r["status"] == o.OPTIMAL:
+            assert np.array_equal(g["x"][k], r["x"]), k
+            assert g["obj"][k] == r["obj"], k
+
+
+@pytest.mark.parametrize("m,n,count", [(2, 5, 7), (8, 16, 33), (16, 40, 20), (32, 64, 40),
+                                        (64, 128, 24), (128, 256, 48)])
+def test_batched_matches_oracle(ctx, m, n, count):
+    A, b, c, basis = _batch(range(100, 100 + count), m, n)
+    g = ctx.simplex_solve_batched(A, b, c, basis, True, n - m)
+    assert (g["status"] == 0).all()
+    _check(g, A, b, c, basis, True, n - m)
+
+
+def test_batched_minimise_unbounded_and_limit(ctx):
+    A, b, c, basis = _batch(range(5), 12, 30)
+    # minimise: the slack vertex is already optimal for c >= 0 (0 pivots) — and with negated
+    # costs the minimise rules (:163-174) do real work
+    g = ctx.simplex_solve_batched(A, b, -c, basis, False, 18)
+    _check(g, A, b, -c, basis, False, 18)
+    g = ctx.simplex_solve_batched(A, b, c, basis, True, 18, max_iter=3)
+    assert (g["status"] == capi.ITER_LIMIT).all()
+    _check(g, A, b, c, basis, True, 18, max_iter=3)
+    Au = A.copy()
+    Au[:, :, 0] = -1.0          # column 0 never limits the ratio test -> unbounded
+    cu = c.copy()
+    cu[:, 0] = 10.0
+    g = ctx.simplex_solve_batched(Au, b, cu, basis, True, 18)
+    assert (g["status"] == capi.UNBOUNDED).all()
+    _check(g, Au, b, cu, basis, True, 18)
+
+
+def test_batched_degenerate_ties(ctx):
+    """Every LP has b = 0 rows: ratios tie at 0 and the keyed scan must keep the first position."""
+    A, b, c, basis = _batch(range(40, 52), 10, 24)
+    b[:, ::2] = 0.0
+    g = ctx.simplex_solve_batched(A, b, c, basis, True, 14)
+    _check(g, A, b, c, basis, True, 14)
+
+
+def test_batched_fallback_general_basis(ctx):
+    """Non-slack starting bases cannot use the LDS-resident kernel; the fallback must agree too."""
+    probs = [lpcases.general_lp(s, 6, 14) for s in (1, 2, 3)]
+    A = np.stack([p[0] for p in probs]); b = np.stack([p[1] for p in probs])
+    c = np.stack([p[2] for p in probs]); basis = np.stack([p[3] for p in probs])
+    n = A.shape[2]
+    g = ctx.simplex_solve_batched(A, b, c, basis, True, n)
+    _check(g, A, b, c, basis, True, n)
+
+
+def test_batched_problem_object_and_timing(ctx):
+    A, b, c, basis = _batch(range(7, 7 + 64), 32, 64)
+    p = ctx.batched_problem(A, b, c, basis, True, 32)
+    ms1 = p.run()
+    d1 = p.download()
+    ms2 = p.run()
+    d2 = p.download()
+    assert ms1 > 0 and ms2 > 0
+    assert np.array_equal(d1["x"], d2["x"]) and np.array_equal(d1["iters"], d2["iters"])
+    _check(d2, A, b, c, basis, True, 32)
+    p.free()
