@@ -72,8 +72,35 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+TESTS_CPP = os.path.join(os.path.dirname(_HERE), "tests", "cpp")
+TESTS_OUT = os.path.join(TESTS_CPP, "_build")
+
+
+def build_cpp_tests(force=False, verbose=False):
+    """tests/cpp/*.cpp -> tests/cpp/_build/<name> (linked against the host + HIP libraries)."""
+    host = build_host(force, verbose)
+    if host is None or not os.path.isdir(TESTS_CPP):
+        return []
+    os.makedirs(TESTS_OUT, exist_ok=True)
+    outs = []
+    for src in _sources(TESTS_CPP, (".cpp",)):
+        exe = os.path.join(TESTS_OUT, os.path.splitext(os.path.basename(src))[0])
+        deps = [src, host, HIP_LIB] + _sources(TESTS_CPP, (".h",)) + _sources(HOST, (".h",))
+        if force or not _newer(exe, deps):
+            cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", HOST, "-I", TESTS_CPP,
+                   "-o", exe, src, "-L", OUT, "-lsimplexmethod_host", "-lsimplexmethod_hip",
+                   "-pthread", "-Wl,-rpath," + OUT]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        outs.append(exe)
+    return outs
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_host(force, verbose)
+    hip, host = build_hip(force, verbose), build_host(force, verbose)
+    build_cpp_tests(force, verbose)
+    return hip, host
 
 
 if __name__ == "__main__":

@@ -129,3 +129,16 @@ def test_bad_arguments(ctx):
     p.free()
     with pytest.raises(capi.LPError):
         ctx.enum_problem(np.ones((40, 70)), np.ones(40), np.ones(70))
+
+
+def test_golden_vectors_gpu(ctx):
+    """tests/golden/enum_cases.json (restatement-derived; see make_golden.py)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "enum_cases.json")
+    enum = json.load(open(path))
+    for case in enum["random"]:
+        A, b, c, _ = lpcases.random_lp(case["seed"], case["m"], case["n"])
+        e = ctx.enum_solve(A, b, c, True, case["n"] - case["m"])
+        assert e["rank"] == case["rank"] and e["basis"].tolist() == case["basis"]
+        assert e["obj"] == case["obj"] and e["counts"] == case["counts"] and e["x"].tolist() == case["x"]

@@ -154,3 +154,17 @@ def test_reset_and_repeat(ctx):
     ms = p.bench_update(0, 0, 10)   # A[0,0] ~ U(0,1): a valid pivot element
     assert ms > 0
     p.free()
+
+
+def test_golden_vectors_gpu(ctx):
+    """tests/golden/simplex_cases.json (restatement-derived, scipy-checked; see make_golden.py)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "simplex_cases.json")
+    for case in json.load(open(path)):
+        A, b, c, basis = lpcases.random_lp(case["seed"], case["m"], case["n"])
+        g = ctx.simplex_solve(A, b, c, basis, True, case["n"] - case["m"])
+        assert g["status"] == 0 and g["iters"] == case["iters"]
+        assert g["basis"].tolist() == case["basis"] and g["obj"] == case["obj"]
+        for j, v in case["x_nonzero"].items():
+            assert g["x"][int(j)] == v

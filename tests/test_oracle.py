@@ -179,3 +179,16 @@ def test_golden_vectors():
         r = o.simplex_tableau(A, b, c, basis, True, case["n"] - case["m"], trace_cap=1 << 14)
         assert r["iters"] == case["iters"] and r["basis"].tolist() == case["basis"]
         assert r["obj"] == case["obj"]
+        assert [list(t) for t in r["trace"][:16]] == case["trace_head"]
+        for j, v in case["x_nonzero"].items():
+            assert r["x"][int(j)] == v
+    enum = json.load(open(os.path.join(GOLDEN, "enum_cases.json")))
+    for case in enum["random"]:
+        A, b, c, _ = lpcases.random_lp(case["seed"], case["m"], case["n"])
+        e = o.enum_solve(A, b, c, True, case["n"] - case["m"])
+        assert e["rank"] == case["rank"] and e["basis"].tolist() == case["basis"]
+        assert e["obj"] == case["obj"] and e["counts"] == case["counts"] and e["x"].tolist() == case["x"]
+    A, b, c, _, _ = lpcases.input_symmetric_lp()
+    for row in enum["input_symmetric"]:
+        st, xB, z = o.enum_subset(A, b, c, row["subset"])
+        assert st == row["verdict"] and xB.tolist() == row["xB"] and z == row["z"]
