@@ -670,18 +670,30 @@ int orc_next_subset(int n, int m, int* subset) {
     return 1;
 }
 
-/* Gauss-Jordan with partial pivoting on W = [A[:,S] | b] (m x (m+1), row-major).
- * Exact operation order (the HIP kernels replay it, also across shared
- * prefixes of consecutive subsets):
- *   for t = 0..m-1:
+/* Per-subset solve of [A[:,S] | b] (m x (m+1), row-major W), columns in ascending order.
+ * Exact operation order (the HIP kernels replay it, also across shared prefixes of
+ * consecutive subsets — everything up to step m-3 depends only on S_0..S_{m-3}):
+ *
+ *   Gauss-Jordan with partial (row) pivoting on the first g = max(m-2, 0) columns:
+ *   for t = 0..g-1:
  *     p   = first row, among rows not yet used as a pivot, of largest |W[i][t]|
  *     piv = W[p][t];  piv == 0 -> singular
  *     inv = 1/piv
  *     every row i != p (used or not): l = -(W[i][t]*inv);
  *                                      W[i][c] = fma(l, W[p][c], W[i][c])  for c > t
  *     row p:                           W[p][c] = W[p][c]*inv               for c > t
- *   singular iff min_t|piv_t| <= DBL_EPSILON * m * max_t|piv_t|
- *   x(S_t) = W[p_t][m];  feasible iff every x >= -1e-9 (a NaN is infeasible)
+ *
+ *   2x2 block on the last two columns a = m-2, b = m-1 and the two unused rows r1 < r2
+ *   (elimination inside the block, then back-substitution into the used rows):
+ *     p = (|W[r2][a]| > |W[r1][a]|) ? r2 : r1 ; q = the other;  piv1 = W[p][a]; inv1 = 1/piv1
+ *     l   = -(W[q][a]*inv1);  wqb = fma(l, W[p][b], W[q][b]);  rq = fma(l, rhs[p], rhs[q])
+ *     piv2 = wqb; inv2 = 1/piv2
+ *     x_b = rq*inv2;          x_a = fma(-W[p][b], x_b, rhs[p]) * inv1
+ *     used row i (pivot row of step t): x(S_t) = fma(-W[i][b], x_b, fma(-W[i][a], x_a, rhs[i]))
+ *   (m == 1: the single pivot piv = W[0][0]; x = rhs[0] * (1/piv).)
+ *
+ *   singular iff some pivot is 0 or min|piv| <= DBL_EPSILON * m * max|piv| over all m pivots
+ *   feasible iff every x >= -1e-9 (a NaN is infeasible)
  *   z = fma(c[S_t], x(S_t), z) for t ascending, from z = 0
  */
 int orc_enum_subset(const double* A, int m, int n, const double* b, const double* c,
@@ -689,11 +701,13 @@ int orc_enum_subset(const double* A, int m, int n, const double* b, const double
     (void)n;
     const int ld = m + 1;
     double Wst[17 * 18];
-    int rowst[32];
-    unsigned char usedst[32];
+    double xst[64];
+    int rowst[64];
+    unsigned char usedst[64];
     double* W = (m <= 17) ? Wst : (double*)xmalloc(sizeof(double) * (size_t)m * ld);
-    int* rowpos = (m <= 32) ? rowst : (int*)xmalloc(sizeof(int) * (size_t)m);
-    unsigned char* used = (m <= 32) ? usedst : (unsigned char*)xmalloc((size_t)m);
+    double* x = (m <= 64) ? xst : (double*)xmalloc(sizeof(double) * (size_t)m);
+    int* rowpos = (m <= 64) ? rowst : (int*)xmalloc(sizeof(int) * (size_t)m);
+    unsigned char* used = (m <= 64) ? usedst : (unsigned char*)xmalloc((size_t)m);
     for (int i = 0; i < m; ++i) {
         for (int t = 0; t < m; ++t) W[i * ld + t] = AT(A, m, i, subset[t]);
         W[i * ld + m] = b[i];
@@ -701,7 +715,8 @@ int orc_enum_subset(const double* A, int m, int n, const double* b, const double
     }
     int status = ORC_SUBSET_FEASIBLE;
     double minp = INFINITY, maxp = 0.0;
-    for (int t = 0; t < m; ++t) {
+    const int g = m >= 2 ? m - 2 : 0;
+    for (int t = 0; t < g; ++t) {
         int p = -1;
         double big = -1.0;
         for (int i = 0; i < m; ++i) {
@@ -723,12 +738,50 @@ int orc_enum_subset(const double* A, int m, int n, const double* b, const double
         used[p] = 1;
         rowpos[t] = p;
     }
+    if (status == ORC_SUBSET_FEASIBLE) {
+        if (m == 1) {
+            const double piv = W[0];
+            const double big = fabs(piv);
+            if (!(big > 0.0)) status = ORC_SUBSET_SINGULAR;
+            minp = maxp = big;
+            x[0] = W[1] * (1.0 / piv);
+        } else {
+            int r1 = -1, r2 = -1;
+            for (int i = 0; i < m; ++i)
+                if (!used[i]) { if (r1 < 0) r1 = i; else r2 = i; }
+            const int ca = m - 2, cb = m - 1;
+            const int p = (fabs(W[r2 * ld + ca]) > fabs(W[r1 * ld + ca])) ? r2 : r1;
+            const int q = (p == r1) ? r2 : r1;
+            const double piv1 = W[p * ld + ca];
+            const double big1 = fabs(piv1);
+            if (!(big1 > 0.0)) status = ORC_SUBSET_SINGULAR;
+            const double inv1 = 1.0 / piv1;
+            const double l = -(W[q * ld + ca] * inv1);
+            const double wqb = fma(l, W[p * ld + cb], W[q * ld + cb]);
+            const double rq = fma(l, W[p * ld + m], W[q * ld + m]);
+            const double big2 = fabs(wqb);
+            if (!(big2 > 0.0)) status = ORC_SUBSET_SINGULAR;
+            const double inv2 = 1.0 / wqb;
+            const double xb = rq * inv2;
+            const double xa = fma(-W[p * ld + cb], xb, W[p * ld + m]) * inv1;
+            if (big1 < minp) minp = big1;
+            if (big1 > maxp) maxp = big1;
+            if (big2 < minp) minp = big2;
+            if (big2 > maxp) maxp = big2;
+            for (int t = 0; t < g; ++t) {
+                const int i = rowpos[t];
+                x[t] = fma(-W[i * ld + cb], xb, fma(-W[i * ld + ca], xa, W[i * ld + m]));
+            }
+            x[ca] = xa;
+            x[cb] = xb;
+        }
+    }
     if (status == ORC_SUBSET_FEASIBLE && minp <= DBL_EPSILON * (double)m * maxp)
         status = ORC_SUBSET_SINGULAR;
     if (status == ORC_SUBSET_FEASIBLE) {
         double z = 0.0;
         for (int t = 0; t < m; ++t) {
-            double xv = W[rowpos[t] * ld + m];
+            const double xv = x[t];
             if (xB_out) xB_out[t] = xv;
             if (!(xv >= -1e-9)) status = ORC_SUBSET_INFEASIBLE; /* Canonical.cpp:171; NaN counts as infeasible */
             z = fma(c[subset[t]], xv, z);
@@ -736,6 +789,7 @@ int orc_enum_subset(const double* A, int m, int n, const double* b, const double
         if (z_out) *z_out = z;
     }
     if (W != Wst) free(W);
+    if (x != xst) free(x);
     if (rowpos != rowst) free(rowpos);
     if (used != usedst) free(used);
     return status;

@@ -96,7 +96,8 @@ double orc_evaluate(const double* c, const double* x, int n);
 /* ---- Enumeration (build-defined) ----------------------------
  * Rank k in [0, C(n,m)) indexes the sorted m-subsets of {0..n-1} in lexicographic
  * order.  Per subset: Gauss-Jordan on [A[:,S] | b] with partial (row) pivoting,
- * columns in ascending order (see lp_oracle.c for the exact operation order);
+ * columns in ascending order, the last two columns solved as a 2x2 block with
+ * back-substitution (see lp_oracle.c for the exact operation order);
  * singular iff a pivot is exactly 0 or min|pivot| <= DBL_EPSILON*m*max|pivot|
  * (Eigen FullPivLU::isInvertible's default threshold, the test the reference
  * applies at SimplexSolover.h:124-126); feasible iff all xB >= -1e-9

@@ -25,8 +25,10 @@ struct GroupBest {
 
 template <int G>
 struct SubsetSolve {
-    double xrow;     // this lane's final rhs (value of the variable pivoted in this row)
-    int P[G];        // P[t] = group-relative lane that became the pivot row of step t
+    double xrow;     // used lanes: value of the variable pivoted in this row (back-substituted)
+    double xa, xb;   // values of the last two columns (2x2 block), uniform in the group
+    int P[G];        // P[t] = group-relative lane that became the pivot row of step t < m-2
+    int sa, sb;      // the last two columns of the subset
     bool singular;
     bool feasible;
 };
@@ -66,17 +68,27 @@ __device__ __forceinline__ void next_subset(int m, int n, int (&S)[G]) {
     }
 }
 
-// Gauss-Jordan with partial pivoting on [A[:,S] | b]; see orc_enum_subset for the
-// operation order this replays.
+// The build-defined per-subset solve; see orc_enum_subset (oracle/lp_oracle.c) for the
+// operation order this replays: Gauss-Jordan with partial pivoting on the first m-2 columns,
+// then the 2x2 block of the last two columns on the two unused rows, then back-substitution.
 template <int G>
 __device__ __forceinline__ void solve_subset(const EnumDev& d, const double* sA, const double* sb,
                                              const int (&S)[G], int gl /* lane in group */,
                                              SubsetSolve<G>& out) {
     const int m = d.m;
+    const int g = m - 2;  // Gauss-Jordan steps (m == 1 is handled at the end)
     const bool active = gl < m;
+    int sa = 0, sbc = 0;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        if (t == m - 2) sa = S[t];
+        if (t == m - 1) sbc = S[t];
+    }
     double W[G];
 #pragma unroll
-    for (int t = 0; t < G; ++t) W[t] = (active && t < m) ? sA[gl * d.lda + S[t]] : 0.0;
+    for (int t = 0; t < G; ++t) W[t] = (active && t < g) ? sA[gl * d.lda + S[t]] : 0.0;
+    double Wa = (active && m >= 2) ? sA[gl * d.lda + sa] : 0.0;
+    double Wb = active ? sA[gl * d.lda + sbc] : 0.0;
     double rhs = active ? sb[gl] : 0.0;
     bool used = !active;
     bool sing = false;
@@ -84,7 +96,7 @@ __device__ __forceinline__ void solve_subset(const EnumDev& d, const double* sA,
 #pragma unroll
     for (int t = 0; t < G; ++t) {
         out.P[t] = 0;
-        if (t < m) {
+        if (t < g) {
             double a = used ? -1.0 : fabs(W[t]);
             int idx = gl;
 #pragma unroll
@@ -106,25 +118,68 @@ __device__ __forceinline__ void solve_subset(const EnumDev& d, const double* sA,
             const bool isp = (gl == p);
 #pragma unroll
             for (int c = t + 1; c < G; ++c) {
-                if (c < m) {
+                if (c < g) {
                     const double pc = __shfl(W[c], p, G);
                     W[c] = isp ? pc * inv : fma(l, pc, W[c]);
                 }
             }
+            const double pa = __shfl(Wa, p, G);
+            Wa = isp ? pa * inv : fma(l, pa, Wa);
+            const double pb = __shfl(Wb, p, G);
+            Wb = isp ? pb * inv : fma(l, pb, Wb);
             const double pr = __shfl(rhs, p, G);
             rhs = isp ? pr * inv : fma(l, pr, rhs);
             if (isp) used = true;
             out.P[t] = p;
         }
     }
+    // ---- the two unused rows r1 < r2 and the 2x2 block
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << gbase);
+    const unsigned long long um = (__ballot(!used) & gmask) >> gbase;
+    double xa = 0.0, xb = 0.0, big1 = 0.0, big2 = 0.0;
+    if (m >= 2) {
+        const int r1 = um ? (int)__builtin_ctzll(um) : 0;
+        const unsigned long long um2 = um & (um - 1);
+        const int r2 = um2 ? (int)__builtin_ctzll(um2) : r1;
+        const double a1 = __shfl(Wa, r1, G), a2 = __shfl(Wa, r2, G);
+        const double b1 = __shfl(Wb, r1, G), b2 = __shfl(Wb, r2, G);
+        const double h1 = __shfl(rhs, r1, G), h2 = __shfl(rhs, r2, G);
+        const bool second = fabs(a2) > fabs(a1);
+        const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
+        const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
+        big1 = fabs(pa);
+        const double inv1 = 1.0 / pa;
+        const double l = -(qa * inv1);
+        const double wqb = fma(l, pb, qb);
+        const double rq = fma(l, ph, qh);
+        big2 = fabs(wqb);
+        const double inv2 = 1.0 / wqb;
+        xb = rq * inv2;
+        xa = fma(-pb, xb, ph) * inv1;
+        if (!(big1 > 0.0) || !(big2 > 0.0)) sing = true;
+        minp = fmin(minp, fmin(big1, big2));
+        maxp = fmax(maxp, fmax(big1, big2));
+        rhs = fma(-Wb, xb, fma(-Wa, xa, rhs));  // back-substitution (meaningful on used rows)
+    } else {  // m == 1: a single pivot
+        const double piv = __shfl(Wb, 0, G), h = __shfl(rhs, 0, G);
+        big1 = fabs(piv);
+        if (!(big1 > 0.0)) sing = true;
+        minp = maxp = big1;
+        xb = h * (1.0 / piv);
+    }
     if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
     out.singular = sing;
     out.xrow = rhs;
-    const bool ok = !active || (rhs >= -1e-9);  // Canonical.cpp:171; NaN is infeasible
+    out.xa = xa;
+    out.xb = xb;
+    out.sa = sa;
+    out.sb = sbc;
+    const bool isused = used && active;
+    bool ok = !isused || (rhs >= -1e-9);  // Canonical.cpp:171; NaN is infeasible
     const unsigned long long bal = __ballot(ok);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << (lane & ~(G - 1)));
-    out.feasible = (bal & gmask) == gmask;
+    out.feasible = ((bal & gmask) == gmask) && (xb >= -1e-9) && (m < 2 || xa >= -1e-9);
 }
 
 template <int G>
@@ -133,11 +188,13 @@ __device__ __forceinline__ double subset_objective(const EnumDev& d, const doubl
     double z = 0.0;
 #pragma unroll
     for (int t = 0; t < G; ++t) {
-        if (t < d.m) {
+        if (t < d.m - 2) {
             const double xv = __shfl(s.xrow, s.P[t], G);
             z = fma(sc[S[t]], xv, z);  // Canonical.cpp:86, ascending column order
         }
     }
+    if (d.m >= 2) z = fma(sc[s.sa], s.xa, z);
+    z = fma(sc[s.sb], s.xb, z);
     return z;
 }
 
@@ -235,7 +292,9 @@ __global__ __launch_bounds__(64) void k_enum_vertex(EnumDev d, unsigned long lon
 #pragma unroll
     for (int t = 0; t < G; ++t) {
         if (t < d.m) {
-            const double xv = __shfl(s.xrow, s.P[t], G);
+            double xv = __shfl(s.xrow, s.P[t], G);
+            if (t == d.m - 2) xv = s.xa;
+            if (t == d.m - 1) xv = s.xb;
             if (gl == 0) {
                 vx[t] = xv;
                 vi[t] = S[t];
