@@ -377,6 +377,13 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dbinom);
     (void)hipFree(p->dev.result); (void)hipFree(p->dev.chunk_best);
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
+    (void)hipFree(p->prefix.level_count); (void)hipFree(p->prefix.overflow);
+    (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab);
+    (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
+    if (p->h_level_count) (void)hipHostFree(p->h_level_count);
+    if (p->h_list_count) (void)hipHostFree(p->h_list_count);
+    if (p->h_overflow) (void)hipHostFree(p->h_overflow);
     if (p->h_result) (void)hipHostFree(p->h_result);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -433,6 +440,29 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
                           hipMemcpyHostToDevice, s));
+    {   // shared-prefix path: small control words, the feasible list, the pair table
+        PrefixDev& pd = p->prefix;
+        pd.list_cap = 1ULL << 22;
+        std::vector<unsigned short> pairtab((size_t)20 * kPairTabStride, 0);
+        for (int R = 2; R < 20; ++R) {
+            int r = 0;
+            for (int qa = 0; qa < R; ++qa)
+                for (int qb = qa + 1; qb < R; ++qb) pairtab[(size_t)R * kPairTabStride + r++] = (unsigned short)(qa | (qb << 8));
+        }
+        LP_TRY(hipMalloc(&pd.level_count, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.root_cursor, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.list, sizeof(unsigned long long) * pd.list_cap));
+        LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
+        LP_TRY(hipMalloc(&pd.scores, sizeof(double) * pd.list_cap));
+        LP_TRY(hipMalloc(&p->dpairtab, sizeof(unsigned short) * pairtab.size()));
+        LP_TRY(hipHostMalloc(&p->h_level_count, sizeof(int)));
+        LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
+        LP_TRY(hipHostMalloc(&p->h_overflow, sizeof(int)));
+        LP_TRY(hipMemcpyAsync(p->dpairtab, pairtab.data(), sizeof(unsigned short) * pairtab.size(),
+                              hipMemcpyHostToDevice, s));
+        pd.pairtab = p->dpairtab;
+    }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY
     d.A = p->dA;
@@ -458,8 +488,18 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     if (rc) return rc;
     double score = -INFINITY;
     uint64_t counts[3] = {0, 0, 0};
+    p->list_valid = false;
+    if (algo == LP_ENUM_ALGO_AUTO)  // the shared-prefix path pays off once the tree is deep and wide
+        algo = (lp_enum_prefix_supported(p) && rank_end - rank_begin >= (1ULL << 20)) ? LP_ENUM_ALGO_PREFIX
+                                                                                        : LP_ENUM_ALGO_DIRECT;
     switch (algo) {
-        case LP_ENUM_ALGO_AUTO:
+        case LP_ENUM_ALGO_PREFIX:
+            if (!lp_enum_prefix_supported(p))
+                LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 16 and 2 <= n-m <= 16");
+            rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
+            if (rc != LP_ITER_LIMIT) break;
+            // buffers or the feasible list were too small for this problem: direct path
+            [[fallthrough]];
         case LP_ENUM_ALGO_DIRECT:
             rc = lp_enum_direct_range(p, rank_begin, rank_end, &score, counts, stats_out);
             break;
@@ -481,6 +521,8 @@ int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_
     int rc = check_range(p, rank_begin, rank_end);
     if (rc) return rc;
     const double star = p->dev.maximize ? zstar : -zstar;
+    if (p->list_valid && p->list_begin == rank_begin && p->list_end == rank_end)
+        return lp_enum_list_first(p, star, tol, rank_out);  // every feasible subset is listed
     return lp_enum_direct_first(p, rank_begin, rank_end, star, tol, rank_out);
 }
 

@@ -308,6 +308,44 @@ __global__ __launch_bounds__(64) void k_enum_vertex(EnumDev d, unsigned long lon
     }
 }
 
+// Objectives of listed ranks (the shared-prefix path's feasible subsets): one group per entry.
+template <int G>
+__global__ __launch_bounds__(256) void k_enum_eval_list(EnumDev d, const unsigned long long* list,
+                                                        unsigned long long count, double* scores) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sA = smem;
+    double* sb = sA + d.m * d.lda;
+    double* sc = sb + d.m;
+    stage_problem(d, sA, sb, sc);
+    const int gl = threadIdx.x & (G - 1);
+    const unsigned long long groups = (unsigned long long)gridDim.x * (blockDim.x / G);
+    unsigned long long e = (unsigned long long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+    double best = -INFINITY;
+    for (; e < count; e += groups) {
+        int S[G];
+        unrank_subset<G>(d, list[e], S);
+        SubsetSolve<G> s;
+        solve_subset<G>(d, sA, sb, S, gl, s);
+        const double z = subset_objective<G>(d, sc, S, s);
+        // listed subsets are feasible by construction; a verdict mismatch would be a bug and
+        // shows up as -inf here
+        const double score = (!s.singular && s.feasible) ? (d.maximize ? z : -z) : -INFINITY;
+        if (gl == 0) scores[e] = score;
+        if (score > best) best = score;
+    }
+    if (gl == 0 && best > -INFINITY) atomicMax(&d.result->best_key, lp_f64_key(best));
+}
+
+__global__ void k_enum_list_first(EnumDev d, const unsigned long long* list, unsigned long long count,
+                                  const double* scores, double star, double tol) {
+    unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long first = ~0ULL;
+    for (; e < count; e += stride)
+        if (scores[e] >= star - tol && list[e] < first) first = list[e];
+    if (first != ~0ULL) atomicMin(&d.result->first_rank, first);
+}
+
 size_t enum_smem_bytes(const EnumDev& d) {
     return sizeof(double) * (size_t)(d.m * d.lda + d.m + d.n) + 4 * sizeof(unsigned long long) + 16;
 }
@@ -441,5 +479,37 @@ int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* su
     }
     *z = hx[kEnumMaxM];
     *verdict = hi[kEnumMaxM];
+    return LP_OPTIMAL;
+}
+
+int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best) {
+    lp_context* ctx = p->ctx;
+    const EnumDev& d = p->dev;
+    const size_t shm = enum_smem_bytes(d);
+    const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(count, 16), (uint64_t)ctx->num_cus * 8);
+    if (d.m <= 16)
+        hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, p->prefix.list,
+                           (unsigned long long)count, p->prefix.scores);
+    else
+        hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, p->prefix.list,
+                           (unsigned long long)count, p->prefix.scores);
+    int rc = fetch_result(p);
+    if (rc) return rc;
+    *score_best = lp_key_f64(p->h_result->best_key);
+    return LP_OPTIMAL;
+}
+
+int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out) {
+    lp_context* ctx = p->ctx;
+    *rank_out = UINT64_MAX;
+    if (p->list_n == 0) return LP_OPTIMAL;
+    int rc = reset_result(p);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(p->list_n, 256), 1024);
+    hipLaunchKernelGGL(k_enum_list_first, grid, 256, 0, ctx->stream, p->dev, p->prefix.list,
+                       (unsigned long long)p->list_n, p->prefix.scores, score_star, tol);
+    rc = fetch_result(p);
+    if (rc) return rc;
+    *rank_out = p->h_result->first_rank;
     return LP_OPTIMAL;
 }

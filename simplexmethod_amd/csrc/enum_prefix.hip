@@ -1,0 +1,566 @@
+// enum_prefix.hip — vertex enumeration with SHARED-PREFIX elimination over the combination
+// tree (LP_ENUM_ALGO_PREFIX).  Results are bit-identical to enum_direct.hip / the oracle's
+// orc_enum_subset: the per-subset solve (Gauss-Jordan with partial pivoting on the first m-2
+// columns in ascending order, then a 2x2 block + back-substitution) depends, up to step t,
+// only on the first t+1 columns of the subset, so all subsets sharing a prefix share that
+// part of the elimination — ~O(m) flops per subset instead of O(m^3).
+//
+// The sorted m-subsets form a tree (depth t = t columns chosen).  A node carries the
+// partially eliminated tableau restricted to the columns still selectable, [W[:, c > last] | rhs]
+// (16 rows x <= n-t+1 columns), the used-row mask and min/max |pivot|.
+//
+//   phase 1  k_enum_expand   levels 0 .. D0 = m-5 breadth-first through HBM: one 16-lane
+//            group (lane = row) per parent streams its columns from HBM, pivots on each
+//            child column and writes the child record.  Cheap (few nodes), bandwidth-shaped.
+//   phase 2  k_enum_sweep    one group per depth-D0 node: three more levels (m-5, m-4, m-3)
+//            live in REGISTERS (lane = row, column slot = static register index; the pivot
+//            column is picked with a select chain, the pivot row is broadcast lane->group).
+//            Depth m-2 nodes ("mu": two unused rows left) are written to LDS, and the last
+//            two columns are then enumerated by ALL lanes of the workgroup, one lane per
+//            subset: 2x2 block solve, back-substitution over the used rows, feasibility.
+//   Feasible subsets are rare; their ranks are appended to a list and their objectives are
+//   evaluated afterwards by the direct solver (enum_direct.hip: k_enum_eval_list), which
+//   also serves pass 2 (tie rule) without a second enumeration.
+//
+// Singular prefixes prune their whole subtree (min|piv| only falls, max|piv| only grows).
+#include <cfloat>
+
+#include "enum_problem.hpp"
+
+namespace {
+
+constexpr int PG = 16;            // lanes per group = max rows
+constexpr int NMX = 16;           // max n - m on this path
+constexpr int META = 8;           // doubles of metadata behind each node record
+constexpr int POOLC = 20;         // LDS columns (16 doubles each) per group for mu tableaus
+constexpr int MAXMU = 10;         // mu descriptors per group per round
+constexpr int SWEEP_THREADS = 256;
+constexpr int SWEEP_GROUPS = SWEEP_THREADS / PG;
+constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
+
+struct NodeMeta {  // 64 bytes, stored behind the columns of a record
+    unsigned long long rank_base;  // rank of the first subset below this node
+    double minp, maxp;             // smallest / largest |pivot| so far
+    int last_col;                  // last chosen column (-1 at the root)
+    unsigned used_mask;            // bit i: row i already used as a pivot row
+    int pad[8];
+};
+static_assert(sizeof(NodeMeta) == META * 8, "NodeMeta must be 64 bytes");
+
+__device__ __forceinline__ size_t rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
+
+__device__ __forceinline__ unsigned long long binom(const EnumDev& d, int nn, int kk) {
+    if (kk < 0 || nn < kk || nn < 0) return 0ULL;
+    return d.binom[nn * kBinomK + kk];
+}
+
+__device__ __forceinline__ unsigned long long overlap(unsigned long long rb, unsigned long long cnt,
+                                                      unsigned long long begin, unsigned long long end) {
+    const unsigned long long lo = rb > begin ? rb : begin;
+    const unsigned long long hi = (rb + cnt) < end ? (rb + cnt) : end;
+    return hi > lo ? hi - lo : 0ULL;
+}
+
+// max over the 16 lanes of a group (DPP row operations), result in every lane of the group
+__device__ __forceinline__ double row_max_f64(double v) {
+    double o;
+#define LP_RSTEP(CTRL)                                                                   \
+    {                                                                                    \
+        const long long b = __double_as_longlong(v);                                     \
+        int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);                           \
+        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);                 \
+        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);                 \
+        o = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);              \
+        v = fmax(v, o);                                                                  \
+    }
+    LP_RSTEP(0xB1)   // quad_perm [1,0,3,2]
+    LP_RSTEP(0x4E)   // quad_perm [2,3,0,1]
+    LP_RSTEP(0x141)  // row_half_mirror
+    LP_RSTEP(0x140)  // row_mirror
+#undef LP_RSTEP
+    return v;
+}
+
+// Partial-pivot row choice for one group: first unused row of largest |w| (strict > keeps the
+// first).  Returns the group-relative lane p and big = |w_p| (big = -1 if no unused row).
+__device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, double& big) {
+    const double a = used ? -1.0 : fabs(w);
+    big = row_max_f64(a);
+    const unsigned long long hit = (__ballot(a == big && !used) >> gbase) & 0xFFFFULL;
+    return hit ? (int)__builtin_ctzll(hit) : 0;
+}
+
+// ---------------------------------------------------------------------------
+// phase 1: expand level t -> t+1 (records in HBM)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
+                                                     const double* src, int nsrc, double* dst,
+                                                     int dst_cap, unsigned long long begin,
+                                                     unsigned long long end) {
+    const int m = d.m, n = d.n;
+    const int gl = threadIdx.x & (PG - 1);
+    const int lane = threadIdx.x & 63, gbase = lane & ~(PG - 1);
+    const int node = blockIdx.x * (blockDim.x / PG) + (threadIdx.x / PG);
+    if (node >= nsrc) return;  // whole group leaves together
+    const double* P = src + (size_t)node * rec_doubles(n, t);
+    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
+    double* const dst0 = dst;
+    const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
+    const double prhs = P[(size_t)(n - t) * PG + gl];
+    const int lim = n - m + t;  // largest column selectable at depth t
+    unsigned long long rb = pm.rank_base;
+    unsigned long long sing = 0ULL;
+    for (int a = pm.last_col + 1; a <= lim; ++a) {
+        const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
+        const unsigned long long ov = overlap(rb, cnt, begin, end);
+        const unsigned long long rb_child = rb;
+        rb += cnt;
+        if (ov == 0ULL) continue;
+        const double w = P[(size_t)(a - t) * PG + gl];
+        double big;
+        const int p = pick_pivot_row(w, prow_used, gbase, big);
+        const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
+        if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
+            sing += ov;  // the whole subtree is singular
+            continue;
+        }
+        int slot = 0;
+        if (gl == 0) slot = atomicAdd(pd.level_count, 1);
+        slot = __shfl(slot, 0, PG);
+        if (slot >= dst_cap) {
+            if (gl == 0) atomicExch(pd.overflow, 1);
+            continue;
+        }
+        double* C = dst0 + (size_t)slot * rec_doubles(n, t + 1);
+        const double piv = __shfl(w, p, PG);
+        const double inv = 1.0 / piv;
+        const double l = -(w * inv);
+        const bool isp = (gl == p);
+        for (int c = a + 1; c < n; ++c) {
+            const double own = P[(size_t)(c - t) * PG + gl];
+            const double pc = __shfl(own, p, PG);
+            C[(size_t)(c - t - 1) * PG + gl] = isp ? pc * inv : fma(l, pc, own);
+        }
+        const double pr = __shfl(prhs, p, PG);
+        C[(size_t)(n - t - 1) * PG + gl] = isp ? pr * inv : fma(l, pr, prhs);
+        if (gl == 0) {
+            NodeMeta cm;
+            cm.rank_base = rb_child;
+            cm.minp = minp;
+            cm.maxp = maxp;
+            cm.last_col = a;
+            cm.used_mask = pm.used_mask | (1u << p);
+            for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+            *reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t)) = cm;
+        }
+    }
+    if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
+}
+
+// root record (depth 0): the original [A | b]
+__global__ void k_enum_root(EnumDev d, double* dst) {
+    const int gl = threadIdx.x;
+    if (gl >= PG) return;
+    for (int c = 0; c < d.n; ++c) dst[(size_t)c * PG + gl] = gl < d.m ? d.A[gl * d.lda + c] : 0.0;
+    dst[(size_t)d.n * PG + gl] = gl < d.m ? d.b[gl] : 0.0;
+    if (gl == 0) {
+        NodeMeta cm;
+        cm.rank_base = 0ULL;
+        cm.minp = INFINITY;
+        cm.maxp = 0.0;
+        cm.last_col = -1;
+        cm.used_mask = 0u;
+        for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+        *reinterpret_cast<NodeMeta*>(dst + (size_t)PG * (d.n + 1)) = cm;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// phase 2: register-resident levels m-5, m-4, m-3; mu in LDS; pairs by all lanes
+// ---------------------------------------------------------------------------
+struct MuDesc {   // 48 bytes
+    unsigned long long rank_base;
+    double minp, maxp;
+    int colbase;   // first pool column (workgroup-wide index)
+    int R;         // remaining columns; column R of the mu block is the rhs
+    int r1, r2;    // the two unused rows
+    int pairbase;  // first slot of this mu's pairs in the round's pair list
+    int pad;
+};
+
+// One Gauss-Jordan pivot on parent slot `ka` (dynamic, uniform in the group): child slot k-1
+// receives the transformed parent slot k for every k > ka.  Returns false if the subtree is
+// singular.  SP = parent slots.
+template <int SP>
+__device__ __forceinline__ bool pivot_level(const double (&P)[SP], double prhs, bool pused, int ka,
+                                            int m, int gl, int gbase, double pminp, double pmaxp,
+                                            double (&C)[SP - 1], double& crhs, bool& cused,
+                                            double& cminp, double& cmaxp) {
+    double w = 0.0;
+#pragma unroll
+    for (int k = 0; k < SP; ++k)
+        if (k == ka) w = P[k];
+    double big;
+    const int p = pick_pivot_row(w, pused, gbase, big);
+    cminp = fmin(pminp, big);
+    cmaxp = fmax(pmaxp, big);
+    if (!(big > 0.0) || cminp <= DBL_EPSILON * (double)m * cmaxp) return false;
+    const double piv = __shfl(w, p, PG);
+    const double inv = 1.0 / piv;
+    const double l = -(w * inv);
+    const bool isp = (gl == p);
+#pragma unroll
+    for (int k = 1; k < SP; ++k) {
+        if (k > ka) {
+            const double pc = __shfl(P[k], p, PG);
+            C[k - 1] = isp ? pc * inv : fma(l, pc, P[k]);
+        }
+    }
+    const double pr = __shfl(prhs, p, PG);
+    crhs = isp ? pr * inv : fma(l, pr, prhs);
+    cused = pused || isp;
+    return true;
+}
+
+__global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixDev pd,
+                                                              const double* roots, int nroots,
+                                                              unsigned long long begin,
+                                                              unsigned long long end) {
+    constexpr int S5 = NMX + 5, S4 = NMX + 4, S3 = NMX + 3;
+    __shared__ __attribute__((aligned(16))) double s_pool[SWEEP_GROUPS * POOLC * PG];
+    __shared__ MuDesc s_desc[SWEEP_GROUPS * MAXMU];
+    __shared__ unsigned char s_pairmu[PAIRCAP];
+    __shared__ int s_npairs, s_nmu;
+
+    const int m = d.m, n = d.n, D0 = m - 5;
+    const int tid = threadIdx.x;
+    const int gl = tid & (PG - 1), grp = tid / PG;
+    const int lane = tid & 63, gbase = lane & ~(PG - 1);
+    const int lim5 = n - 5, lim4 = n - 4, lim3 = n - 3;  // largest child column per level
+
+    double R5[S5], R4[S4], R3[S3];
+    double rhs5 = 0.0, rhs4 = 0.0, rhs3 = 0.0;
+    bool used5 = true, used4 = true, used3 = true;
+    double minp5 = 0.0, maxp5 = 0.0, minp4 = 0.0, maxp4 = 0.0, minp3 = 0.0, maxp3 = 0.0;
+    unsigned long long rb5 = 0, rb4 = 0, rb3 = 0;  // rank base of the NEXT child at each level
+    int a5 = 0, a4 = 0, a3 = 0;                    // last child column taken at each level
+    bool have5 = false, have4 = false, have3 = false, active = true;
+    unsigned long long cntF = 0, cntI = 0, cntS = 0;  // per-lane (pair phase)
+    unsigned long long cntSg = 0;                     // per-group (pruned singular subtrees)
+    __shared__ unsigned long long s_cnt[3];
+    if (tid < 3) s_cnt[tid] = 0ULL;
+
+    for (;;) {
+        if (tid == 0) {
+            s_npairs = 0;
+            s_nmu = 0;
+        }
+        __syncthreads();
+        // ---------------- advance this group's walk to a depth m-3 node with children left
+        while (__any(active && !have3)) {
+            const bool need = active && !have3;
+            if (need && !have5) {
+                int idx = 0;
+                if (gl == 0) idx = atomicAdd(pd.root_cursor, 1);
+                idx = __shfl(idx, 0, PG);
+                if (idx >= nroots) {
+                    active = false;
+                } else {
+                    const double* P = roots + (size_t)idx * rec_doubles(n, D0);
+                    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D0 + 1));
+#pragma unroll
+                    for (int k = 0; k < S5; ++k) R5[k] = (k < n - D0) ? P[(size_t)k * PG + gl] : 0.0;
+                    rhs5 = P[(size_t)(n - D0) * PG + gl];
+                    used5 = (gl >= m) || ((pm.used_mask >> gl) & 1u);
+                    minp5 = pm.minp;
+                    maxp5 = pm.maxp;
+                    rb5 = pm.rank_base;
+                    a5 = pm.last_col;
+                    have5 = true;
+                    have4 = false;
+                }
+            }
+            if (need && active && have5 && !have4) {
+                const int a = a5 + 1;
+                if (a > lim5) {
+                    have5 = false;
+                } else {
+                    const unsigned long long cnt = binom(d, n - 1 - a, 4);
+                    const unsigned long long ov = overlap(rb5, cnt, begin, end);
+                    if (ov != 0ULL) {
+                        if (pivot_level<S5>(R5, rhs5, used5, a - D0, m, gl, gbase, minp5, maxp5, R4, rhs4,
+                                            used4, minp4, maxp4)) {
+                            have4 = true;
+                            a4 = a;
+                            rb4 = rb5;
+                        } else {
+                            cntSg += ov;
+                        }
+                    }
+                    a5 = a;
+                    rb5 += cnt;
+                }
+            }
+            if (need && active && have4 && !have3) {
+                const int a = a4 + 1;
+                if (a > lim4) {
+                    have4 = false;
+                } else {
+                    const unsigned long long cnt = binom(d, n - 1 - a, 3);
+                    const unsigned long long ov = overlap(rb4, cnt, begin, end);
+                    if (ov != 0ULL) {
+                        if (pivot_level<S4>(R4, rhs4, used4, a - (D0 + 1), m, gl, gbase, minp4, maxp4, R3,
+                                            rhs3, used3, minp3, maxp3)) {
+                            have3 = true;
+                            a3 = a;
+                            rb3 = rb4;
+                        } else {
+                            cntSg += ov;
+                        }
+                    }
+                    a4 = a;
+                    rb4 += cnt;
+                }
+            }
+        }
+        // ---------------- produce mu nodes (depth m-2) of the current depth m-3 node into LDS
+        {
+            int poolused = 0, nmine = 0;
+            while (have3) {
+                const int a = a3 + 1;
+                if (a > lim3) {
+                    have3 = false;
+                    break;
+                }
+                const int Rmu = n - 1 - a;
+                if (poolused + Rmu + 1 > POOLC || nmine >= MAXMU) break;  // resume next round
+                const unsigned long long cnt = (unsigned long long)(Rmu * (Rmu - 1) / 2);
+                const unsigned long long ov = overlap(rb3, cnt, begin, end);
+                const unsigned long long rbmu = rb3;
+                a3 = a;
+                rb3 += cnt;
+                if (ov == 0ULL) continue;
+                const int ka = a - (D0 + 2);
+                double w = 0.0;
+#pragma unroll
+                for (int k = 0; k < S3; ++k)
+                    if (k == ka) w = R3[k];
+                double big;
+                const int p = pick_pivot_row(w, used3, gbase, big);
+                const double minp = fmin(minp3, big), maxp = fmax(maxp3, big);
+                if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
+                    cntSg += ov;
+                    continue;
+                }
+                const double piv = __shfl(w, p, PG);
+                const double inv = 1.0 / piv;
+                const double l = -(w * inv);
+                const bool isp = (gl == p);
+                const int colbase = grp * POOLC + poolused;
+                double* pool = s_pool + (size_t)colbase * PG;
+#pragma unroll
+                for (int k = 1; k < S3; ++k) {
+                    if (k > ka && k - ka - 1 < Rmu) {
+                        const double pc = __shfl(R3[k], p, PG);
+                        pool[(k - ka - 1) * PG + gl] = isp ? pc * inv : fma(l, pc, R3[k]);
+                    }
+                }
+                const double pr = __shfl(rhs3, p, PG);
+                pool[Rmu * PG + gl] = isp ? pr * inv : fma(l, pr, rhs3);
+                const bool usedmu = used3 || isp;
+                const unsigned long long um = (__ballot(!usedmu) >> gbase) & 0xFFFFULL;
+                int base = 0;
+                if (gl == 0) {
+                    base = atomicAdd(&s_npairs, (int)cnt);
+                    MuDesc md;
+                    md.rank_base = rbmu;
+                    md.minp = minp;
+                    md.maxp = maxp;
+                    md.colbase = colbase;
+                    md.R = Rmu;
+                    md.r1 = um ? (int)__builtin_ctzll(um) : 0;
+                    const unsigned long long um2 = um & (um - 1);
+                    md.r2 = um2 ? (int)__builtin_ctzll(um2) : md.r1;
+                    md.pairbase = base;
+                    md.pad = 0;
+                    s_desc[grp * MAXMU + nmine] = md;
+                }
+                base = __shfl(base, 0, PG);
+                for (int r = gl; r < (int)cnt; r += PG)
+                    if (base + r < PAIRCAP) s_pairmu[base + r] = (unsigned char)(grp * MAXMU + nmine);
+                poolused += Rmu + 1;
+                ++nmine;
+            }
+        }
+        __syncthreads();
+        const int npairs = s_npairs < PAIRCAP ? s_npairs : PAIRCAP;
+        // ---------------- pairs: one lane per subset (2x2 block + back-substitution)
+        for (int q = tid; q < npairs; q += SWEEP_THREADS) {
+            const int mi = s_pairmu[q];
+            const MuDesc md = s_desc[mi];
+            const int r = q - md.pairbase;
+            const unsigned pk = pd.pairtab[md.R * kPairTabStride + r];
+            const int qa = (int)(pk & 0xFF), qb = (int)(pk >> 8);
+            const double* colA = s_pool + (size_t)(md.colbase + qa) * PG;
+            const double* colB = s_pool + (size_t)(md.colbase + qb) * PG;
+            const double* colH = s_pool + (size_t)(md.colbase + md.R) * PG;
+            const double a1 = colA[md.r1], a2 = colA[md.r2];
+            const double b1 = colB[md.r1], b2 = colB[md.r2];
+            const double h1 = colH[md.r1], h2 = colH[md.r2];
+            const bool second = fabs(a2) > fabs(a1);
+            const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
+            const double qa_ = second ? a1 : a2, qb_ = second ? b1 : b2, qh = second ? h1 : h2;
+            const double big1 = fabs(pa);
+            const double inv1 = 1.0 / pa;
+            const double l = -(qa_ * inv1);
+            const double wqb = fma(l, pb, qb_);
+            const double rq = fma(l, ph, qh);
+            const double big2 = fabs(wqb);
+            const double inv2 = 1.0 / wqb;
+            const double xb = rq * inv2;
+            const double xa = fma(-pb, xb, ph) * inv1;
+            const double minp = fmin(md.minp, fmin(big1, big2));
+            const double maxp = fmax(md.maxp, fmax(big1, big2));
+            const bool sing = !(big1 > 0.0) || !(big2 > 0.0) || (minp <= DBL_EPSILON * (double)m * maxp);
+            bool feas = (xa >= -1e-9) && (xb >= -1e-9);
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                if (i < m && i != md.r1 && i != md.r2) {
+                    const double x = fma(-colB[i], xb, fma(-colA[i], xa, colH[i]));
+                    feas = feas && (x >= -1e-9);
+                }
+            }
+            const unsigned long long rank = md.rank_base + (unsigned long long)r;
+            if (rank >= begin && rank < end) {
+                if (sing) {
+                    ++cntS;
+                } else if (!feas) {
+                    ++cntI;
+                } else {
+                    ++cntF;
+                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                    if (at < pd.list_cap) pd.list[at] = rank;
+                }
+            }
+        }
+        if (s_npairs > PAIRCAP && tid == 0) atomicExch(pd.overflow, 2);
+        if (!__syncthreads_or(active || have3)) break;
+    }
+    // ---------------- counts: block-level first, then one device atomic per counter
+    if (gl == 0) cntS += cntSg;
+    if (cntF) atomicAdd(&s_cnt[0], cntF);
+    if (cntI) atomicAdd(&s_cnt[1], cntI);
+    if (cntS) atomicAdd(&s_cnt[2], cntS);
+    __syncthreads();
+    if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+
+static size_t host_rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
+
+bool lp_enum_prefix_supported(const lp_enum_problem* p) {
+    const EnumDev& d = p->dev;
+    return d.m >= 6 && d.m <= PG && (d.n - d.m) <= NMX && (d.n - d.m) >= 2;
+}
+
+int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                         uint64_t counts[3], lp_enum_stats* stats) {
+    lp_context* ctx = p->ctx;
+    const EnumDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    const int m = d.m, n = d.n, D0 = m - 5;
+    PrefixDev& pd = p->prefix;
+    // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0)
+    const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
+    const size_t need = (size_t)nodes_max * host_rec_doubles(n, D0) * sizeof(double);
+    const size_t need_prev = (size_t)lp_host_binom(n - m + D0 - 1, D0 - 1) * host_rec_doubles(n, D0 - 1) * sizeof(double);
+    if (p->prefix_buf_bytes[0] < need) {
+        if (p->prefix_buf[0]) (void)hipFree(p->prefix_buf[0]);
+        p->prefix_buf[0] = nullptr;
+        p->prefix_buf_bytes[0] = 0;
+        size_t free_b = 0, total_b = 0;
+        LP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        if (need + need_prev > free_b / 10 * 9) return LP_ITER_LIMIT;  // caller falls back to direct
+        LP_HIP(ctx, hipMalloc(&p->prefix_buf[0], need));
+        p->prefix_buf_bytes[0] = need;
+    }
+    if (p->prefix_buf_bytes[1] < need_prev) {
+        if (p->prefix_buf[1]) (void)hipFree(p->prefix_buf[1]);
+        p->prefix_buf[1] = nullptr;
+        p->prefix_buf_bytes[1] = 0;
+        LP_HIP(ctx, hipMalloc(&p->prefix_buf[1], need_prev));
+        p->prefix_buf_bytes[1] = need_prev;
+    }
+    // depth-D0 records always end in buffer 0; levels alternate so that level D0 lands there
+    EnumResult r;
+    std::memset(&r, 0, sizeof(r));
+    r.best_key = lp_f64_key(-INFINITY);
+    r.first_rank = ~0ULL;
+    *p->h_result = r;
+    LP_HIP(ctx, hipMemcpyAsync(d.result, p->h_result, sizeof(r), hipMemcpyHostToDevice, s));
+    LP_HIP(ctx, hipMemsetAsync(pd.list_count, 0, sizeof(unsigned long long), s));
+    LP_HIP(ctx, hipMemsetAsync(pd.overflow, 0, sizeof(int), s));
+    LP_HIP(ctx, hipMemsetAsync(pd.root_cursor, 0, sizeof(int), s));
+    LP_HIP(ctx, hipEventRecord(p->ev0, s));
+    int launches = 0;
+    int cur = (D0 % 2 == 0) ? 0 : 1;  // buffer of level 0, so that level D0 is buffer 0
+    hipLaunchKernelGGL(k_enum_root, 1, 64, 0, s, d, p->prefix_buf[cur]);
+    ++launches;
+    int count = 1;
+    for (int t = 0; t < D0; ++t) {
+        LP_HIP(ctx, hipMemsetAsync(pd.level_count, 0, sizeof(int), s));
+        const int nxt = cur ^ 1;
+        const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1) * sizeof(double));
+        const int cap = cap64 > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)cap64;
+        const int groups_per_block = 256 / PG;
+        hipLaunchKernelGGL(k_enum_expand, lp_ceil_div(count, groups_per_block), 256, 0, s, d, pd, t,
+                           p->prefix_buf[cur], count, p->prefix_buf[nxt], cap, (unsigned long long)begin,
+                           (unsigned long long)end);
+        ++launches;
+        LP_HIP(ctx, hipMemcpyAsync(p->h_level_count, pd.level_count, sizeof(int), hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipStreamSynchronize(s));
+        count = *p->h_level_count;
+        if (count > cap) count = cap;
+        cur = nxt;
+        if (count == 0) break;
+    }
+    if (count > 0) {
+        const int grid = std::min(count, ctx->num_cus * 8);
+        hipLaunchKernelGGL(k_enum_sweep, lp_ceil_div(grid, 1), SWEEP_THREADS, 0, s, d, pd,
+                           p->prefix_buf[cur], count, (unsigned long long)begin, (unsigned long long)end);
+        ++launches;
+    }
+    LP_HIP(ctx, hipEventRecord(p->ev1, s));
+    LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
+    LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    LP_HIP(ctx, hipMemcpyAsync(p->h_overflow, pd.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    LP_HIP(ctx, hipGetLastError());
+    if (*p->h_overflow != 0 || *p->h_list_count > pd.list_cap) return LP_ITER_LIMIT;  // fall back
+    float ms = 0.f;
+    LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    // ---- objectives of the (few) feasible subsets, by the direct solver
+    const uint64_t nfeas = *p->h_list_count;
+    double best = -INFINITY;
+    if (nfeas) {
+        int rc = lp_enum_eval_list(p, nfeas, &best);
+        if (rc) return rc;
+    }
+    p->list_valid = true;
+    p->list_begin = begin;
+    p->list_end = end;
+    p->list_n = nfeas;
+    *score_best = best;
+    for (int k = 0; k < 3; ++k) counts[k] = p->h_result->counts[k];
+    if (stats) {
+        stats->kernel_ms = ms;
+        stats->subsets = end - begin;
+        stats->launches = launches;
+    }
+    return LP_OPTIMAL;
+}

@@ -47,6 +47,20 @@ struct EnumDev {
     double* chunk_best;             // per-chunk best score of the last pass 1
 };
 
+constexpr int kPairTabStride = 192;  // >= C(19,2)
+
+// Shared-prefix path (enum_prefix.hip)
+struct PrefixDev {
+    int* level_count;                 // records written by the current expand launch
+    int* overflow;                    // != 0: a buffer was too small, the caller falls back
+    int* root_cursor;                 // next depth-D0 record to be taken by a sweep group
+    unsigned long long* list;         // ranks of feasible subsets
+    unsigned long long* list_count;
+    unsigned long long list_cap;
+    double* scores;                   // objective score of each list entry (after evaluation)
+    const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
+};
+
 struct lp_enum_problem {
     lp_context* ctx = nullptr;
     EnumDev dev{};
@@ -65,6 +79,17 @@ struct lp_enum_problem {
     // vertex scratch
     double* dvx = nullptr;  // kEnumMaxM xB values + 1 objective
     int* dvi = nullptr;     // kEnumMaxM subset + 1 verdict
+    // shared-prefix path
+    PrefixDev prefix{};
+    double* prefix_buf[2] = {nullptr, nullptr};
+    size_t prefix_buf_bytes[2] = {0, 0};
+    unsigned short* dpairtab = nullptr;
+    int* h_level_count = nullptr;              // pinned
+    unsigned long long* h_list_count = nullptr;  // pinned
+    int* h_overflow = nullptr;                 // pinned
+    bool list_valid = false;                   // the feasible list of the last prefix pass 1 is usable
+    uint64_t list_begin = 0, list_end = 0, list_n = 0;
+    int last_algo = 0;
 };
 
 // enum_direct.hip
@@ -74,3 +99,13 @@ int lp_enum_direct_first(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
                          double tol, uint64_t* rank_out);
 int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* subset, double* z,
                           int* verdict);
+// objectives of the prefix path's feasible list (scores[] and the best score)
+int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
+// smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
+int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
+
+// enum_prefix.hip
+bool lp_enum_prefix_supported(const lp_enum_problem* p);
+// LP_ITER_LIMIT = "could not run here (memory / list overflow), use the direct path"
+int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                         uint64_t counts[3], lp_enum_stats* stats);

@@ -142,3 +142,82 @@ def test_golden_vectors_gpu(ctx):
         e = ctx.enum_solve(A, b, c, True, case["n"] - case["m"])
         assert e["rank"] == case["rank"] and e["basis"].tolist() == case["basis"]
         assert e["obj"] == case["obj"] and e["counts"] == case["counts"] and e["x"].tolist() == case["x"]
+
+
+# ---- shared-prefix path (enum_prefix.hip): same answers as the oracle, bit for bit ------------
+
+PREFIX_SHAPES = [(6, 12, 51), (7, 16, 52), (8, 16, 53), (10, 20, 54), (6, 20, 55), (8, 24, 56),
+                 (12, 20, 57), (16, 20, 58)]
+
+
+@pytest.mark.parametrize("m,n,seed", PREFIX_SHAPES)
+def test_prefix_matches_oracle(ctx, m, n, seed):
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, stats = p.range(0, total, capi.ENUM_PREFIX)
+    assert gcounts == counts and sum(gcounts) == total
+    assert rc == st and gz == z
+    k = o.enum_first_within(A, b, c, True, 0, total, z)
+    assert p.first_within(0, total, z) == k
+    v = p.vertex(k)
+    _, xB, zz = o.enum_subset(A, b, c, o.unrank(n, m, k))
+    assert v["obj"] == zz and np.array_equal(v["x"][v["basis"]], xB)
+    # and the direct kernel agrees with the prefix kernel
+    rc2, dz, dcounts, _ = p.range(0, total, capi.ENUM_DIRECT)
+    assert (rc2, dz, dcounts) == (rc, gz, gcounts)
+    p.free()
+
+
+def test_prefix_shards_and_minimise(ctx):
+    rng = np.random.default_rng(77)
+    m, n = 7, 17
+    A = rng.normal(size=(m, n))
+    b = rng.normal(size=m)
+    c = rng.normal(size=n)
+    total = o.binom(n, m)
+    for maximize in (True, False):
+        st, z, counts = o.enum_range(A, b, c, maximize, 0, total)
+        p = ctx.enum_problem(A, b, c, maximize)
+        rc, gz, gcounts, _ = p.range(0, total, capi.ENUM_PREFIX)
+        assert (rc, gz, gcounts) == (st, z, counts)
+        for parts in (2, 3, 8):
+            cuts = [total * k // parts for k in range(parts + 1)]
+            zs, cs, firsts = [], np.zeros(3, dtype=np.int64), []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                r1, zz, cc, _ = p.range(lo, hi, capi.ENUM_PREFIX)
+                ro, zo, co = o.enum_range(A, b, c, maximize, lo, hi)
+                assert (r1, zz, cc) == (ro, zo, co)
+                zs.append(zz)
+                cs += cc
+                firsts.append(p.first_within(lo, hi, z))
+            assert cs.tolist() == counts
+            assert min(firsts) == o.enum_first_within(A, b, c, maximize, 0, total, z)
+        p.free()
+
+
+def test_prefix_singular_subtrees(ctx):
+    rng = np.random.default_rng(9)
+    m, n = 6, 14
+    A = rng.uniform(size=(m, n))
+    A[:, 3] = A[:, 1]          # duplicate column: every subset holding both is singular
+    A[:, 7] = 0.0              # zero column
+    A[:, 12] = 2.0 * A[:, 10]  # and late in the subset, to hit the 2x2 block
+    b = rng.uniform(1, 2, size=m)
+    c = rng.uniform(size=n)
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    assert counts[2] > 0
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, _ = p.range(0, total, capi.ENUM_PREFIX)
+    assert (rc, gz, gcounts) == (st, z, counts)
+    p.free()
+
+
+def test_prefix_rejects_unsupported_shapes(ctx):
+    A, b, c, _ = lpcases.random_lp(1, 3, 7)
+    p = ctx.enum_problem(A, b, c, True)
+    with pytest.raises(capi.LPError):
+        p.range(0, p.total, capi.ENUM_PREFIX)
+    p.free()
