@@ -127,6 +127,7 @@ void lp_simplex_free(lp_simplex_problem* p) {
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (hipEvent_t e : p->upd_events) (void)hipEventDestroy(e);
     delete p;
 }
 

@@ -24,6 +24,7 @@
 //
 // Singular prefixes prune their whole subtree (min|piv| only falls, max|piv| only grows).
 #include <cfloat>
+#include <cstdlib>
 
 #include "enum_problem.hpp"
 
@@ -81,6 +82,14 @@ __device__ __forceinline__ double row_max_f64(double v) {
     return v;
 }
 
+// Broadcast of lane (gbase + p)'s value to its group: addr = (gbase + p) << 2, computed once per pivot.
+__device__ __forceinline__ double bcast16(double v, int addr) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xFFFFFFFFLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Partial-pivot row choice for one group: first unused row of largest |w| (strict > keeps the
 // first).  Returns the group-relative lane p and big = |w_p| (big = -1 if no unused row).
 __device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, double& big) {
@@ -94,7 +103,8 @@ __device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, do
 // phase 1: expand level t -> t+1 (records in HBM)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
-                                                     const double* src, int nsrc, double* dst,
+                                                     const double* __restrict__ src, int nsrc,
+                                                     double* __restrict__ dst,
                                                      int dst_cap, unsigned long long begin,
                                                      unsigned long long end) {
     const int m = d.m, n = d.n;
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         const double inv = 1.0 / piv;
         const double l = -(w * inv);
         const bool isp = (gl == p);
+#pragma unroll 4
         for (int c = a + 1; c < n; ++c) {
             const double own = P[(size_t)(c - t) * PG + gl];
             const double pc = __shfl(own, p, PG);
@@ -205,19 +216,72 @@ __device__ __forceinline__ bool pivot_level(const double (&P)[SP], double prhs, 
     cminp = fmin(pminp, big);
     cmaxp = fmax(pmaxp, big);
     if (!(big > 0.0) || cminp <= DBL_EPSILON * (double)m * cmaxp) return false;
-    const double piv = __shfl(w, p, PG);
+    const int addr = (gbase + p) << 2;
+    const double piv = bcast16(w, addr);
     const double inv = 1.0 / piv;
-    const double l = -(w * inv);
     const bool isp = (gl == p);
+    // one fma per element: rows i != p take fma(l, pc, own); the pivot row takes pc*inv, written
+    // as fma(inv, pc, -0.0) (exactly the product, sign of zero included)
+    const double lx = isp ? inv : -(w * inv);
+    // columns in static blocks of four, skipped when no group of the wave needs them; inside a
+    // block nothing is predicated, so the broadcasts are issued back to back (dead columns of a
+    // group just receive values nobody reads)
 #pragma unroll
-    for (int k = 1; k < SP; ++k) {
-        if (k > ka) {
-            const double pc = __shfl(P[k], p, PG);
-            C[k - 1] = isp ? pc * inv : fma(l, pc, P[k]);
+    for (int kb = 1; kb < SP; kb += 4) {
+        if (__any(kb + 3 > ka)) {
+#pragma unroll
+            for (int k = kb; k < kb + 4 && k < SP; ++k) {
+                const double pc = bcast16(P[k], addr);
+                C[k - 1] = fma(lx, pc, isp ? -0.0 : P[k]);
+            }
         }
     }
-    const double pr = __shfl(prhs, p, PG);
-    crhs = isp ? pr * inv : fma(l, pr, prhs);
+    const double pr = bcast16(prhs, addr);
+    crhs = fma(lx, pr, isp ? -0.0 : prhs);
+    cused = pused || isp;
+    return true;
+}
+
+// The same pivot with the parent read straight from its HBM record (depth D0 roots are not
+// kept in registers: a root is pivoted only once per ~4 depth m-3 nodes and stays L2-hot).
+template <int SP>
+__device__ __forceinline__ bool pivot_from_record(const double* __restrict__ P, int ncols, double prhs,
+                                                  bool pused, int ka, int m, int gl, int gbase,
+                                                  double pminp, double pmaxp, double (&C)[SP - 1],
+                                                  double& crhs, bool& cused, double& cminp,
+                                                  double& cmaxp) {
+    const double w = P[(size_t)ka * PG + gl];
+    double big;
+    const int p = pick_pivot_row(w, pused, gbase, big);
+    cminp = fmin(pminp, big);
+    cmaxp = fmax(pmaxp, big);
+    if (!(big > 0.0) || cminp <= DBL_EPSILON * (double)m * cmaxp) return false;
+    const int addr = (gbase + p) << 2;
+    const double piv = bcast16(w, addr);
+    const double inv = 1.0 / piv;
+    const bool isp = (gl == p);
+    const double lx = isp ? inv : -(w * inv);
+#pragma unroll
+    for (int kb = 1; kb < SP; kb += 4) {
+        if (__any(kb + 3 > ka)) {
+            double own[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + j;
+                own[j] = (k < SP && k < ncols) ? P[(size_t)k * PG + gl] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + j;
+                if (k < SP) {
+                    const double pc = bcast16(own[j], addr);
+                    C[k - 1] = fma(lx, pc, isp ? -0.0 : own[j]);
+                }
+            }
+        }
+    }
+    const double pr = bcast16(prhs, addr);
+    crhs = fma(lx, pr, isp ? -0.0 : prhs);
     cused = pused || isp;
     return true;
 }
@@ -238,7 +302,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
     const int lane = tid & 63, gbase = lane & ~(PG - 1);
     const int lim5 = n - 5, lim4 = n - 4, lim3 = n - 3;  // largest child column per level
 
-    double R5[S5], R4[S4], R3[S3];
+    const double* rec5 = roots;  // record of the current depth-D0 root
+    double R4[S4], R3[S3];
     double rhs5 = 0.0, rhs4 = 0.0, rhs3 = 0.0;
     bool used5 = true, used4 = true, used3 = true;
     double minp5 = 0.0, maxp5 = 0.0, minp4 = 0.0, maxp4 = 0.0, minp3 = 0.0, maxp3 = 0.0;
@@ -256,6 +321,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
             s_nmu = 0;
         }
         __syncthreads();
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (pd.dbg) t0 = __builtin_readcyclecounter();
         // ---------------- advance this group's walk to a depth m-3 node with children left
         while (__any(active && !have3)) {
             const bool need = active && !have3;
@@ -268,8 +335,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                 } else {
                     const double* P = roots + (size_t)idx * rec_doubles(n, D0);
                     const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D0 + 1));
-#pragma unroll
-                    for (int k = 0; k < S5; ++k) R5[k] = (k < n - D0) ? P[(size_t)k * PG + gl] : 0.0;
+                    rec5 = P;
                     rhs5 = P[(size_t)(n - D0) * PG + gl];
                     used5 = (gl >= m) || ((pm.used_mask >> gl) & 1u);
                     minp5 = pm.minp;
@@ -288,8 +354,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     const unsigned long long cnt = binom(d, n - 1 - a, 4);
                     const unsigned long long ov = overlap(rb5, cnt, begin, end);
                     if (ov != 0ULL) {
-                        if (pivot_level<S5>(R5, rhs5, used5, a - D0, m, gl, gbase, minp5, maxp5, R4, rhs4,
-                                            used4, minp4, maxp4)) {
+                        if (pivot_from_record<S5>(rec5, n - D0, rhs5, used5, a - D0, m, gl, gbase, minp5,
+                                                  maxp5, R4, rhs4, used4, minp4, maxp4)) {
                             have4 = true;
                             a4 = a;
                             rb4 = rb5;
@@ -323,6 +389,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                 }
             }
         }
+        if (pd.dbg) t1 = __builtin_readcyclecounter();
         // ---------------- produce mu nodes (depth m-2) of the current depth m-3 node into LDS
         {
             int poolused = 0, nmine = 0;
@@ -352,21 +419,34 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     cntSg += ov;
                     continue;
                 }
-                const double piv = __shfl(w, p, PG);
+                const int addr = (gbase + p) << 2;
+                const double piv = bcast16(w, addr);
                 const double inv = 1.0 / piv;
-                const double l = -(w * inv);
                 const bool isp = (gl == p);
+                const double lx = isp ? inv : -(w * inv);
                 const int colbase = grp * POOLC + poolused;
                 double* pool = s_pool + (size_t)colbase * PG;
 #pragma unroll
-                for (int k = 1; k < S3; ++k) {
-                    if (k > ka && k - ka - 1 < Rmu) {
-                        const double pc = __shfl(R3[k], p, PG);
-                        pool[(k - ka - 1) * PG + gl] = isp ? pc * inv : fma(l, pc, R3[k]);
+                for (int kb = 1; kb < S3; kb += 4) {
+                    if (__any(kb + 3 > ka)) {
+                        double v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = kb + j;
+                            if (k < S3) {
+                                const double pc = bcast16(R3[k], addr);
+                                v[j] = fma(lx, pc, isp ? -0.0 : R3[k]);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = kb + j;
+                            if (k < S3 && k > ka && k - ka - 1 < Rmu) pool[(k - ka - 1) * PG + gl] = v[j];
+                        }
                     }
                 }
-                const double pr = __shfl(rhs3, p, PG);
-                pool[Rmu * PG + gl] = isp ? pr * inv : fma(l, pr, rhs3);
+                const double pr = bcast16(rhs3, addr);
+                pool[Rmu * PG + gl] = fma(lx, pr, isp ? -0.0 : rhs3);
                 const bool usedmu = used3 || isp;
                 const unsigned long long um = (__ballot(!usedmu) >> gbase) & 0xFFFFULL;
                 int base = 0;
@@ -393,6 +473,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
             }
         }
         __syncthreads();
+        if (pd.dbg) t2 = __builtin_readcyclecounter();
         const int npairs = s_npairs < PAIRCAP ? s_npairs : PAIRCAP;
         // ---------------- pairs: one lane per subset (2x2 block + back-substitution)
         for (int q = tid; q < npairs; q += SWEEP_THREADS) {
@@ -442,6 +523,14 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     if (at < pd.list_cap) pd.list[at] = rank;
                 }
             }
+        }
+        if (pd.dbg && tid == 0) {
+            t3 = __builtin_readcyclecounter();
+            atomicAdd(&pd.dbg[0], t1 - t0);
+            atomicAdd(&pd.dbg[1], t2 - t1);
+            atomicAdd(&pd.dbg[2], t3 - t2);
+            atomicAdd(&pd.dbg[3], 1ULL);
+            atomicAdd(&pd.dbg[4], (unsigned long long)npairs);
         }
         if (s_npairs > PAIRCAP && tid == 0) atomicExch(pd.overflow, 2);
         if (!__syncthreads_or(active || have3)) break;
@@ -506,6 +595,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     LP_HIP(ctx, hipMemsetAsync(pd.list_count, 0, sizeof(unsigned long long), s));
     LP_HIP(ctx, hipMemsetAsync(pd.overflow, 0, sizeof(int), s));
     LP_HIP(ctx, hipMemsetAsync(pd.root_cursor, 0, sizeof(int), s));
+    if (getenv("LP_ENUM_DEBUG") && !pd.dbg) {
+        LP_HIP(ctx, hipMalloc(&pd.dbg, 64));
+    }
+    if (pd.dbg) LP_HIP(ctx, hipMemsetAsync(pd.dbg, 0, 64, s));
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     int launches = 0;
     int cur = (D0 % 2 == 0) ? 0 : 1;  // buffer of level 0, so that level D0 is buffer 0
@@ -541,6 +634,12 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     LP_HIP(ctx, hipMemcpyAsync(p->h_overflow, pd.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipStreamSynchronize(s));
     LP_HIP(ctx, hipGetLastError());
+    if (pd.dbg) {
+        unsigned long long h[8];
+        LP_HIP(ctx, hipMemcpy(h, pd.dbg, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[enum_prefix] rounds %llu  cycles/round: advance %.0f produce %.0f pairs %.0f  pairs/round %.1f\n",
+                h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3]);
+    }
     if (*p->h_overflow != 0 || *p->h_list_count > pd.list_cap) return LP_ITER_LIMIT;  // fall back
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));

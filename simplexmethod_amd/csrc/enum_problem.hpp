@@ -59,6 +59,7 @@ struct PrefixDev {
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
     const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
+    unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
 };
 
 struct lp_enum_problem {

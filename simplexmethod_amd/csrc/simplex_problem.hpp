@@ -59,6 +59,7 @@ struct lp_simplex_problem {
     SimplexState* h_state = nullptr;  // pinned
     std::vector<double> h_c;      // objective coefficients (Canonical::Evaluate on the host)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> upd_events;  // 2 per timed rank-J update launch (look-ahead path)
     int init_status = LP_OPTIMAL; // LP_SINGULAR if the initial basis was singular
     int last_status = -100;
     int last_iters = 0;
