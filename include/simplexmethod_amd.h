@@ -109,6 +109,10 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
 int lp_simplex_reset(lp_simplex_problem* p);
 int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
                    lp_simplex_stats* stats_out);
+/* on != 0: the next runs bracket every tableau-update launch with HIP events so that
+ * lp_simplex_stats::update_ms / update_launches are filled (costs ~1-2 us per launch; off by
+ * default, in which case those two fields are 0).                                         */
+int lp_simplex_profile(lp_simplex_problem* p, int on);
 /* trace_*: first trace_cap pivots (entering column, leaving POSITION); tableau_out:
  * (m+1) x (n+1) row-major, rows by basis position, row m = reduced costs,
  * column n = xB.  Every pointer may be NULL.                                      */
@@ -121,6 +125,13 @@ void lp_simplex_free(lp_simplex_problem* p);
  * restored afterwards).  ms_per_launch = HIP-event time / iters.                  */
 int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,
                           float* ms_per_launch_out);
+
+/* The same for the look-ahead path's rank-J update: the selector stages one batch of J pivots
+ * on the problem's initial tableau (call after lp_simplex_reset), then the update launch is
+ * replayed `iters` times between two HIP events.  *pivots_per_launch_out = J actually staged;
+ * algorithmic bytes per launch = J * 16*m*(n+1).  State is restored afterwards.            */
+int lp_bench_rankj_update(lp_simplex_problem* p, int iters, float* ms_per_launch_out,
+                          int* pivots_per_launch_out);
 
 /* Diagnostic (not part of the drop-in surface): first call with cap_pivots > 0 turns the
  * look-ahead selector's per-phase cycle stamps on; a later call copies 8 stamps per pivot

@@ -52,9 +52,11 @@ SIGNATURES = {
                                     C.POINTER(_vp)]),
     "lp_simplex_reset": (C.c_int, [_vp]),
     "lp_simplex_run": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.POINTER(SimplexStats)]),
+    "lp_simplex_profile": (C.c_int, [_vp, C.c_int]),
     "lp_simplex_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, C.c_int, _dp]),
     "lp_simplex_free": (None, [_vp]),
     "lp_bench_rank1_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp]),
+    "lp_bench_rankj_update": (C.c_int, [_vp, C.c_int, _fp, _ip]),
     "lp_debug_simplex_stamps": (C.c_int, [_vp, C.c_int, _u64p]),
     "lp_simplex_solve_batched": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _ip,
                                            C.c_int, C.c_int, C.c_double, C.c_int, _dp, _ip, _dp,
@@ -271,6 +273,9 @@ class SimplexProblem:
     def reset(self):
         self.ctx.check(self.ctx.lib.lp_simplex_reset(self.h))
 
+    def profile(self, on=True):
+        self.ctx.check(self.ctx.lib.lp_simplex_profile(self.h, int(on)))
+
     def run(self, eps=EPS, max_iter=MAX_ITER, algo=SIMPLEX_AUTO):
         st = SimplexStats()
         rc = self.ctx.check(self.ctx.lib.lp_simplex_run(self.h, eps, max_iter, algo, C.byref(st)))
@@ -292,6 +297,12 @@ class SimplexProblem:
         ms = C.c_float(0.0)
         self.ctx.check(self.ctx.lib.lp_bench_rank1_update(self.h, row, col, iters, C.byref(ms)))
         return ms.value
+
+    def bench_update_rankj(self, iters):
+        ms = C.c_float(0.0)
+        piv = C.c_int(0)
+        self.ctx.check(self.ctx.lib.lp_bench_rankj_update(self.h, iters, C.byref(ms), C.byref(piv)))
+        return ms.value, piv.value
 
     def free(self):
         if getattr(self, "h", None):

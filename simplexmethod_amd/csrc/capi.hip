@@ -281,6 +281,12 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     }
 }
 
+int lp_simplex_profile(lp_simplex_problem* p, int on) {
+    if (!p) return LP_BAD_ARG;
+    p->profile_updates = on != 0;
+    return LP_OPTIMAL;
+}
+
 int lp_simplex_download(lp_simplex_problem* p, double* x_out, int* basis_out, double* obj_out,
                         int* trace_enter, int* trace_leave, int trace_cap, double* tableau_out) {
     if (!p) return LP_BAD_ARG;
@@ -364,6 +370,13 @@ int lp_bench_rank1_update(lp_simplex_problem* p, int row, int col, int iters,
     if (!p) return LP_BAD_ARG;
     LP_HIP(p->ctx, hipSetDevice(p->ctx->device));
     return lp_simplex_bench_update(p, row, col, iters, ms_per_launch_out);
+}
+
+int lp_bench_rankj_update(lp_simplex_problem* p, int iters, float* ms_per_launch_out,
+                          int* pivots_per_launch_out) {
+    if (!p) return LP_BAD_ARG;
+    LP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    return lp_lookahead_bench_update(p, iters, ms_per_launch_out, pivots_per_launch_out);
 }
 
 // ===========================================================================

@@ -241,50 +241,70 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
 }
 
 // rank-J update, in place: t <- eta_{count-1}( ... eta_0(t) ... ) per element.
-constexpr int LU_TX = 64;  // column pairs per block
+// A block owns a LU_ROWS x (2*LU_TX) tile of the tableau.  The eta operands of the whole batch
+// that touch the tile — J eta-column entries per tile row, J pivot-row entries per tile column —
+// are staged once in LDS (18 KB at J = 16), so per launch the tableau is read and written once
+// and the eta traffic is a fraction of that; each thread then applies the J fused multiply-adds
+// to its LU_RPT rows x one 16-B column pair in registers.
+constexpr int LU_TX = 64;    // column pairs per block (128 columns)
 constexpr int LU_TY = 4;
-constexpr int LU_RPT = 2;  // rows per thread
+constexpr int LU_RPT = 4;    // rows per thread
+constexpr int LU_ROWS = LU_TY * LU_RPT;  // 16 rows per block
+constexpr int LU_JMAX = 16;  // upper bound of LookDev::J
 
 __global__ __launch_bounds__(LU_TX* LU_TY) void k_look_update(SimplexDev d, LookDev la) {
     const int count = *la.count;
     if (count == 0) return;
+    __shared__ __attribute__((aligned(16))) double s_pr[LU_JMAX][2 * LU_TX];
+    __shared__ double s_l[LU_JMAX][LU_ROWS];
+    __shared__ int s_piv[2 * LU_JMAX];
     const int ld2 = d.ld >> 1;
-    const int jp = blockIdx.x * LU_TX + threadIdx.x;
-    if (jp >= ld2) return;
     const int rows = d.m + 1;
-    const int i0 = (blockIdx.y * LU_TY + threadIdx.y) * LU_RPT;
+    const int tid = threadIdx.y * LU_TX + threadIdx.x;
+    const int col0 = blockIdx.x * 2 * LU_TX;   // first column of the tile
+    const int row0 = blockIdx.y * LU_ROWS;
+    for (int k = tid; k < count * 2 * LU_TX; k += LU_TX * LU_TY) {
+        const int q = k / (2 * LU_TX), j = k - q * 2 * LU_TX;
+        s_pr[q][j] = (col0 + j < d.ld) ? la.etaP[(size_t)q * d.ld + col0 + j] : 0.0;
+    }
+    for (int k = tid; k < count * LU_ROWS; k += LU_TX * LU_TY) {
+        const int q = k / LU_ROWS, i = k - q * LU_ROWS;
+        s_l[q][i] = (row0 + i < rows) ? la.etaL[(size_t)q * la.rows_pad + row0 + i] : 0.0;
+    }
+    if (tid < 2 * count) s_piv[tid] = la.piv[tid];
+    const int jp = blockIdx.x * LU_TX + threadIdx.x;
+    const bool live = jp < ld2;
+    const int i0 = row0 + threadIdx.y * LU_RPT;
     double2* T2 = reinterpret_cast<double2*>(d.T);
     double2 t[LU_RPT];
 #pragma unroll
     for (int k = 0; k < LU_RPT; ++k)
-        if (i0 + k < rows) t[k] = T2[(size_t)(i0 + k) * ld2 + jp];
+        t[k] = (live && i0 + k < rows) ? T2[(size_t)(i0 + k) * ld2 + jp] : make_double2(0.0, 0.0);
+    __syncthreads();
     for (int q = 0; q < count; ++q) {
-        const int e = la.piv[2 * q], r = la.piv[2 * q + 1];
-        const double2 pr = reinterpret_cast<const double2*>(la.etaP + (size_t)q * d.ld)[jp];
-        const double* lq = la.etaL + (size_t)q * la.rows_pad;
+        const int e = s_piv[2 * q], r = s_piv[2 * q + 1];
         const int je = e >> 1;
+        const double2 pr = *reinterpret_cast<const double2*>(&s_pr[q][2 * threadIdx.x]);
 #pragma unroll
         for (int k = 0; k < LU_RPT; ++k) {
             const int i = i0 + k;
-            if (i < rows) {
-                const double l = lq[i];
-                if (i == r) {
-                    t[k].x = t[k].x * l;
-                    t[k].y = t[k].y * l;
-                } else {
-                    t[k].x = fma(l, pr.x, t[k].x);
-                    t[k].y = fma(l, pr.y, t[k].y);
-                }
-                if (jp == je) {
-                    const double unit = (i == r) ? 1.0 : 0.0;
-                    if (e & 1) t[k].y = unit; else t[k].x = unit;
-                }
+            const double lk = s_l[q][threadIdx.y * LU_RPT + k];
+            if (i == r) {
+                t[k].x = t[k].x * lk;
+                t[k].y = t[k].y * lk;
+            } else {
+                t[k].x = fma(lk, pr.x, t[k].x);
+                t[k].y = fma(lk, pr.y, t[k].y);
+            }
+            if (jp == je) {
+                const double unit = (i == r) ? 1.0 : 0.0;
+                if (e & 1) t[k].y = unit; else t[k].x = unit;
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < LU_RPT; ++k)
-        if (i0 + k < rows) T2[(size_t)(i0 + k) * ld2 + jp] = t[k];
+        if (live && i0 + k < rows) T2[(size_t)(i0 + k) * ld2 + jp] = t[k];
 }
 
 // dvec <- row m of T, rhs <- column n of T (after upload / crash / reset)
@@ -338,7 +358,7 @@ int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter,
     const LookDev& la = p->look;
     hipStream_t s = ctx->stream;
     const size_t shm = sel_lds_bytes(d.m, d.n, la.J);
-    const dim3 ugrid(lp_ceil_div(d.ld / 2, LU_TX), lp_ceil_div(d.m + 1, LU_TY * LU_RPT));
+    const dim3 ugrid(lp_ceil_div(d.ld / 2, LU_TX), lp_ceil_div(d.m + 1, LU_ROWS));
     int launches = 0;
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_look_state_init, 1, 1, 0, s, d, eps, max_iter);
@@ -357,9 +377,9 @@ int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter,
     for (;;) {
         for (int k = 0; k < batches; ++k) {
             hipLaunchKernelGGL(k_look_select, 1, SEL_THREADS, shm, s, d, la);
-            if (timed < kMaxTimed) LP_HIP(ctx, hipEventRecord(p->upd_events[2 * timed], s));
+            if (p->profile_updates && timed < kMaxTimed) LP_HIP(ctx, hipEventRecord(p->upd_events[2 * timed], s));
             hipLaunchKernelGGL(k_look_update, ugrid, dim3(LU_TX, LU_TY), 0, s, d, la);
-            if (timed < kMaxTimed) {
+            if (p->profile_updates && timed < kMaxTimed) {
                 LP_HIP(ctx, hipEventRecord(p->upd_events[2 * timed + 1], s));
                 ++timed;
             }
@@ -397,4 +417,45 @@ int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter,
         stats->bytes_per_pivot = 16.0 * (double)d.m * (double)(d.n + 1);
     }
     return status;
+}
+
+// Micro-benchmark of the rank-J update alone: stage one batch of J pivots on the problem's
+// current tableau with the selector, then replay the update launch `iters` times between two
+// HIP events (the same etas are re-applied, so values drift — irrelevant for timing; the
+// tableau and solver state are restored afterwards).
+int lp_lookahead_bench_update(lp_simplex_problem* p, int iters, float* ms_per_launch, int* pivots_out) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    const LookDev& la = p->look;
+    hipStream_t s = ctx->stream;
+    if (la.J < 1 || iters <= 0) LP_FAIL(ctx, LP_BAD_ARG, "look-ahead path unavailable for this problem");
+    int rc = lp_lookahead_prepare(p);
+    if (rc) return rc;
+    const size_t shm = sel_lds_bytes(d.m, d.n, la.J);
+    const dim3 ugrid(lp_ceil_div(d.ld / 2, LU_TX), lp_ceil_div(d.m + 1, LU_ROWS));
+    LP_HIP(ctx, hipMemcpyAsync(p->dscratchT, d.T, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_look_state_init, 1, 1, 0, s, d, 1e-9, 1 << 30);
+    lp_lookahead_init_vectors(p);
+    hipLaunchKernelGGL(k_look_select, 1, SEL_THREADS, shm, s, d, la);
+    int count = 0;
+    LP_HIP(ctx, hipMemcpyAsync(&count, la.count, sizeof(int), hipMemcpyDeviceToHost, s));
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    if (count <= 0) LP_FAIL(ctx, LP_BAD_ARG, "no pivot could be staged on the current tableau");
+    for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(k_look_update, ugrid, dim3(LU_TX, LU_TY), 0, s, d, la);
+    LP_HIP(ctx, hipEventRecord(p->ev0, s));
+    for (int k = 0; k < iters; ++k) hipLaunchKernelGGL(k_look_update, ugrid, dim3(LU_TX, LU_TY), 0, s, d, la);
+    LP_HIP(ctx, hipEventRecord(p->ev1, s));
+    LP_HIP(ctx, hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / (float)iters;
+    if (pivots_out) *pivots_out = count;
+    // restore: tableau, basis bookkeeping (the selector moved it), staged-count
+    LP_HIP(ctx, hipMemcpyAsync(d.T, p->dscratchT, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipMemcpyAsync(d.basis, p->dbasis0, sizeof(int) * (size_t)d.m, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipMemcpyAsync(d.nonbasic, p->dnonbasic0, (size_t)d.n, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipMemsetAsync(la.count, 0, sizeof(int), s));
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    LP_HIP(ctx, hipGetLastError());
+    return LP_OPTIMAL;
 }

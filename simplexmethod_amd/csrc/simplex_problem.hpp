@@ -60,6 +60,7 @@ struct lp_simplex_problem {
     std::vector<double> h_c;      // objective coefficients (Canonical::Evaluate on the host)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> upd_events;  // 2 per timed rank-J update launch (look-ahead path)
+    bool profile_updates = false;        // lp_simplex_profile: bracket update launches with events
     int init_status = LP_OPTIMAL; // LP_SINGULAR if the initial basis was singular
     int last_status = -100;
     int last_iters = 0;
@@ -77,3 +78,4 @@ int lp_lookahead_pick_j(int m, int n);
 int lp_lookahead_prepare(lp_simplex_problem* p);
 int lp_lookahead_init_vectors(lp_simplex_problem* p);
 int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
+int lp_lookahead_bench_update(lp_simplex_problem* p, int iters, float* ms_per_launch, int* pivots_out);
