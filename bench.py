@@ -203,16 +203,25 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # LP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the
+    # collectives run over gloo on the CPU and ranks share devices round-robin.  The driver's
+    # multi-GPU runs use the default: nccl (= RCCL over xGMI), one device per rank.
+    backend = os.environ.get("LP_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
+    reduce_device = "cpu" if backend == "gloo" else f"cuda:{device_index}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        comm = lpdist.TorchComm(f"cuda:{local_rank}")
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device_index}"))
+        comm = lpdist.TorchComm(reduce_device)
     else:
         comm = lpdist.LocalComm()
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device_index)
     m, n = args.enum_m, args.enum_n
     A, b, c, _ = capi.gen_lp(0, m, n)
     ep = ctx.enum_problem(A, b, c, True)
@@ -242,7 +251,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
