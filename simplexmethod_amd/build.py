@@ -44,7 +44,8 @@ def build_hip(force=False, verbose=False):
     deps = srcs + _sources(CSRC, (".hpp",)) + _sources(INCLUDE, (".h",))
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", HIP_LIB] + srcs
+    extra = os.environ.get("LP_HIPCC_EXTRA", "").split()
+    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

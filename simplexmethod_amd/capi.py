@@ -81,7 +81,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.HIP_LIB
+    # LP_LIB_PATH: A/B experiments with an alternative build of the same library
+    return os.environ.get("LP_LIB_PATH") or _build.HIP_LIB
 
 
 def load():

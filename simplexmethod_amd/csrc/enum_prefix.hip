@@ -37,7 +37,8 @@ constexpr int POOLC = 20;         // LDS columns (16 doubles each) per group for
 constexpr int MAXMU = 10;         // mu descriptors per group per round
 constexpr int SWEEP_THREADS = 256;
 constexpr int SWEEP_GROUPS = SWEEP_THREADS / PG;
-constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
+constexpr int PAIRCAP = 3072;
+constexpr int kHole = -2;         // NodeMeta::last_col of a slot whose subtree was pruned     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
 
 struct NodeMeta {  // 64 bytes, stored behind the columns of a record
     unsigned long long rank_base;  // rank of the first subset below this node
@@ -104,20 +105,38 @@ __device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, do
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
                                                      const double* __restrict__ src, int nsrc,
-                                                     double* __restrict__ dst,
-                                                     int dst_cap, unsigned long long begin,
+                                                     double* __restrict__ dst, int dst_cap,
+                                                     unsigned long long begin,
                                                      unsigned long long end) {
     const int m = d.m, n = d.n;
     const int gl = threadIdx.x & (PG - 1);
     const int lane = threadIdx.x & 63, gbase = lane & ~(PG - 1);
     const int node = blockIdx.x * (blockDim.x / PG) + (threadIdx.x / PG);
-    if (node >= nsrc) return;  // whole group leaves together
-    const double* P = src + (size_t)node * rec_doubles(n, t);
+    const double* P = src + (size_t)(node < nsrc ? node : 0) * rec_doubles(n, t);
     const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
-    double* const dst0 = dst;
+    const bool valid = node < nsrc && pm.last_col != kHole;
+    const int lim = n - m + t;  // largest column selectable at depth t
+    // ---- children whose rank interval meets [begin, end): one slot each, allocated with a
+    // single atomic per WAVE (a per-child atomic on one counter serialises the whole level)
+    int nchild = 0;
+    if (valid) {
+        unsigned long long rbc = pm.rank_base;
+        for (int a = pm.last_col + 1; a <= lim; ++a) {
+            const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
+            if (overlap(rbc, cnt, begin, end) != 0ULL) ++nchild;
+            rbc += cnt;
+        }
+    }
+    const int g0 = __shfl(nchild, 0, 64), g1 = __shfl(nchild, 16, 64), g2 = __shfl(nchild, 32, 64),
+              g3 = __shfl(nchild, 48, 64);
+    int wbase = 0;
+    if (lane == 0 && g0 + g1 + g2 + g3 > 0) wbase = atomicAdd(pd.level_count, g0 + g1 + g2 + g3);
+    wbase = __shfl(wbase, 0, 64);
+    const int gidx = lane >> 4;
+    int slot = wbase + (gidx > 0 ? g0 : 0) + (gidx > 1 ? g1 : 0) + (gidx > 2 ? g2 : 0);
+    if (!valid) return;  // whole group leaves together (no wave-level operation below)
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
     const double prhs = P[(size_t)(n - t) * PG + gl];
-    const int lim = n - m + t;  // largest column selectable at depth t
     unsigned long long rb = pm.rank_base;
     unsigned long long sing = 0ULL;
     for (int a = pm.last_col + 1; a <= lim; ++a) {
@@ -126,34 +145,35 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         const unsigned long long rb_child = rb;
         rb += cnt;
         if (ov == 0ULL) continue;
+        const int myslot = slot++;
+        if (myslot >= dst_cap) {
+            if (gl == 0) atomicExch(pd.overflow, 1);
+            continue;
+        }
+        double* C = dst + (size_t)myslot * rec_doubles(n, t + 1);
+        NodeMeta* cmeta = reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t));
         const double w = P[(size_t)(a - t) * PG + gl];
         double big;
         const int p = pick_pivot_row(w, prow_used, gbase, big);
         const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
         if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
-            sing += ov;  // the whole subtree is singular
+            sing += ov;  // the whole subtree is singular: leave a hole
+            if (gl == 0) cmeta->last_col = kHole;
             continue;
         }
-        int slot = 0;
-        if (gl == 0) slot = atomicAdd(pd.level_count, 1);
-        slot = __shfl(slot, 0, PG);
-        if (slot >= dst_cap) {
-            if (gl == 0) atomicExch(pd.overflow, 1);
-            continue;
-        }
-        double* C = dst0 + (size_t)slot * rec_doubles(n, t + 1);
-        const double piv = __shfl(w, p, PG);
+        const int addr = (gbase + p) << 2;
+        const double piv = bcast16(w, addr);
         const double inv = 1.0 / piv;
-        const double l = -(w * inv);
         const bool isp = (gl == p);
+        const double lx = isp ? inv : -(w * inv);
 #pragma unroll 4
         for (int c = a + 1; c < n; ++c) {
             const double own = P[(size_t)(c - t) * PG + gl];
-            const double pc = __shfl(own, p, PG);
-            C[(size_t)(c - t - 1) * PG + gl] = isp ? pc * inv : fma(l, pc, own);
+            const double pc = bcast16(own, addr);
+            C[(size_t)(c - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own);
         }
-        const double pr = __shfl(prhs, p, PG);
-        C[(size_t)(n - t - 1) * PG + gl] = isp ? pr * inv : fma(l, pr, prhs);
+        const double pr = bcast16(prhs, addr);
+        C[(size_t)(n - t - 1) * PG + gl] = fma(lx, pr, isp ? -0.0 : prhs);
         if (gl == 0) {
             NodeMeta cm;
             cm.rank_base = rb_child;
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             cm.last_col = a;
             cm.used_mask = pm.used_mask | (1u << p);
             for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
-            *reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t)) = cm;
+            *cmeta = cm;
         }
     }
     if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
@@ -199,6 +219,37 @@ struct MuDesc {   // 48 bytes
     int pad;
 };
 
+// P[ka] for a dynamic (group-uniform) ka: binary select tree on the bits of ka (depth log2 SP
+// instead of a chain of SP dependent selects).
+#ifndef LP_SEL_TREE
+#define LP_SEL_TREE 0
+#endif
+#ifndef LP_STATIC_ROOTS
+#define LP_STATIC_ROOTS 0
+#endif
+template <int SP>
+__device__ __forceinline__ double select_slot(const double (&P)[SP], int ka) {
+#if !LP_SEL_TREE
+    double w = 0.0;
+#pragma unroll
+    for (int k = 0; k < SP; ++k)
+        if (k == ka) w = P[k];
+    return w;
+#endif
+    constexpr int N1 = (SP + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+    double v1[N1], v2[N2], v3[N3], v4[N4];
+#pragma unroll
+    for (int j = 0; j < N1; ++j) v1[j] = ((ka & 1) && 2 * j + 1 < SP) ? P[2 * j + 1 < SP ? 2 * j + 1 : 0] : P[2 * j];
+#pragma unroll
+    for (int j = 0; j < N2; ++j) v2[j] = ((ka & 2) && 2 * j + 1 < N1) ? v1[2 * j + 1 < N1 ? 2 * j + 1 : 0] : v1[2 * j];
+#pragma unroll
+    for (int j = 0; j < N3; ++j) v3[j] = ((ka & 4) && 2 * j + 1 < N2) ? v2[2 * j + 1 < N2 ? 2 * j + 1 : 0] : v2[2 * j];
+#pragma unroll
+    for (int j = 0; j < N4; ++j) v4[j] = ((ka & 8) && 2 * j + 1 < N3) ? v3[2 * j + 1 < N3 ? 2 * j + 1 : 0] : v3[2 * j];
+    static_assert(N4 <= 2, "select_slot handles up to 32 slots");
+    return ((ka & 16) && N4 > 1) ? v4[N4 > 1 ? 1 : 0] : v4[0];
+}
+
 // One Gauss-Jordan pivot on parent slot `ka` (dynamic, uniform in the group): child slot k-1
 // receives the transformed parent slot k for every k > ka.  Returns false if the subtree is
 // singular.  SP = parent slots.
@@ -207,10 +258,7 @@ __device__ __forceinline__ bool pivot_level(const double (&P)[SP], double prhs, 
                                             int m, int gl, int gbase, double pminp, double pmaxp,
                                             double (&C)[SP - 1], double& crhs, bool& cused,
                                             double& cminp, double& cmaxp) {
-    double w = 0.0;
-#pragma unroll
-    for (int k = 0; k < SP; ++k)
-        if (k == ka) w = P[k];
+    const double w = select_slot<SP>(P, ka);
     double big;
     const int p = pick_pivot_row(w, pused, gbase, big);
     cminp = fmin(pminp, big);
@@ -310,6 +358,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
     unsigned long long rb5 = 0, rb4 = 0, rb3 = 0;  // rank base of the NEXT child at each level
     int a5 = 0, a4 = 0, a3 = 0;                    // last child column taken at each level
     bool have5 = false, have4 = false, have3 = false, active = true;
+    int next_root = blockIdx.x * SWEEP_GROUPS + grp;
     unsigned long long cntF = 0, cntI = 0, cntS = 0;  // per-lane (pair phase)
     unsigned long long cntSg = 0;                     // per-group (pruned singular subtrees)
     __shared__ unsigned long long s_cnt[3];
@@ -323,18 +372,29 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
         __syncthreads();
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (pd.dbg) t0 = __builtin_readcyclecounter();
-        // ---------------- advance this group's walk to a depth m-3 node with children left
+        // ---------------- advance this group's walk to a depth m-3 node with children left.
+        // One such node per group per round: the four groups of a wave stay in step (all walk,
+        // then all produce); letting each group fill its pool from several nodes desynchronises
+        // them and serialises the wave (measured: 1.3x slower).
         while (__any(active && !have3)) {
             const bool need = active && !have3;
             if (need && !have5) {
+                // roots are dealt round-robin to the groups of the grid: consecutive records
+                // (similar subtree sizes) go to different groups, and no atomic sits on the path
+#if LP_STATIC_ROOTS
+                const int idx = next_root;
+                next_root += gridDim.x * SWEEP_GROUPS;
+#else
                 int idx = 0;
                 if (gl == 0) idx = atomicAdd(pd.root_cursor, 1);
                 idx = __shfl(idx, 0, PG);
+#endif
                 if (idx >= nroots) {
                     active = false;
                 } else {
                     const double* P = roots + (size_t)idx * rec_doubles(n, D0);
                     const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D0 + 1));
+                    if (pm.last_col == kHole) continue;  // pruned slot (group-uniform)
                     rec5 = P;
                     rhs5 = P[(size_t)(n - D0) * PG + gl];
                     used5 = (gl >= m) || ((pm.used_mask >> gl) & 1u);
@@ -400,7 +460,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     break;
                 }
                 const int Rmu = n - 1 - a;
-                if (poolused + Rmu + 1 > POOLC || nmine >= MAXMU) break;  // resume next round
+                if (poolused + Rmu + 1 > POOLC || nmine >= MAXMU) break;  // pool full: resume next round
                 const unsigned long long cnt = (unsigned long long)(Rmu * (Rmu - 1) / 2);
                 const unsigned long long ov = overlap(rb3, cnt, begin, end);
                 const unsigned long long rbmu = rb3;
@@ -408,10 +468,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                 rb3 += cnt;
                 if (ov == 0ULL) continue;
                 const int ka = a - (D0 + 2);
-                double w = 0.0;
-#pragma unroll
-                for (int k = 0; k < S3; ++k)
-                    if (k == ka) w = R3[k];
+                const double w = select_slot<S3>(R3, ka);
                 double big;
                 const int p = pick_pivot_row(w, used3, gbase, big);
                 const double minp = fmin(minp3, big), maxp = fmax(maxp3, big);
@@ -623,8 +680,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         if (count == 0) break;
     }
     if (count > 0) {
-        const int grid = std::min(count, ctx->num_cus * 8);
-        hipLaunchKernelGGL(k_enum_sweep, lp_ceil_div(grid, 1), SWEEP_THREADS, 0, s, d, pd,
+        // one workgroup per CU (the kernel's registers allow one resident workgroup per CU); roots
+        // are dealt round-robin to the grid's groups
+        const int grid = std::min(lp_ceil_div(count, SWEEP_GROUPS), ctx->num_cus);
+        hipLaunchKernelGGL(k_enum_sweep, grid, SWEEP_THREADS, 0, s, d, pd,
                            p->prefix_buf[cur], count, (unsigned long long)begin, (unsigned long long)end);
         ++launches;
     }
