@@ -334,7 +334,7 @@ __device__ __forceinline__ bool pivot_from_record(const double* __restrict__ P, 
     return true;
 }
 
-__global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixDev pd,
+__global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, PrefixDev pd,
                                                               const double* roots, int nroots,
                                                               unsigned long long begin,
                                                               unsigned long long end) {
@@ -351,15 +351,21 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
     const int lim5 = n - 5, lim4 = n - 4, lim3 = n - 3;  // largest child column per level
 
     const double* rec5 = roots;  // record of the current depth-D0 root
-    double R4[S4], R3[S3];
-    double rhs5 = 0.0, rhs4 = 0.0, rhs3 = 0.0;
+    double R4[S4];            // depth m-4 node, one register per selectable column
+    // depth m-3 node: NOT materialised (it would cost 38 more VGPRs and halve the occupancy);
+    // only its pivot (row address, multiplier) and rhs are kept, and its columns are
+    // re-derived from R4 with one extra fma where they are needed
+    int addr4 = 0;
+    double lx4 = 0.0;
+    bool isp4 = false;
+    double rhs4 = 0.0, rhs3 = 0.0;   // the root's rhs / min / max |pivot| are re-read from its record
     bool used5 = true, used4 = true, used3 = true;
-    double minp5 = 0.0, maxp5 = 0.0, minp4 = 0.0, maxp4 = 0.0, minp3 = 0.0, maxp3 = 0.0;
+    double minp4 = 0.0, maxp4 = 0.0, minp3 = 0.0, maxp3 = 0.0;
     unsigned long long rb5 = 0, rb4 = 0, rb3 = 0;  // rank base of the NEXT child at each level
     int a5 = 0, a4 = 0, a3 = 0;                    // last child column taken at each level
     bool have5 = false, have4 = false, have3 = false, active = true;
     int next_root = blockIdx.x * SWEEP_GROUPS + grp;
-    unsigned long long cntF = 0, cntI = 0, cntS = 0;  // per-lane (pair phase)
+    unsigned int cntF = 0, cntI = 0, cntS = 0;        // per-lane (pair phase; far below 2^32 each)
     unsigned long long cntSg = 0;                     // per-group (pruned singular subtrees)
     __shared__ unsigned long long s_cnt[3];
     if (tid < 3) s_cnt[tid] = 0ULL;
@@ -396,10 +402,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D0 + 1));
                     if (pm.last_col == kHole) continue;  // pruned slot (group-uniform)
                     rec5 = P;
-                    rhs5 = P[(size_t)(n - D0) * PG + gl];
                     used5 = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-                    minp5 = pm.minp;
-                    maxp5 = pm.maxp;
                     rb5 = pm.rank_base;
                     a5 = pm.last_col;
                     have5 = true;
@@ -414,8 +417,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     const unsigned long long cnt = binom(d, n - 1 - a, 4);
                     const unsigned long long ov = overlap(rb5, cnt, begin, end);
                     if (ov != 0ULL) {
-                        if (pivot_from_record<S5>(rec5, n - D0, rhs5, used5, a - D0, m, gl, gbase, minp5,
-                                                  maxp5, R4, rhs4, used4, minp4, maxp4)) {
+                        const NodeMeta* pm5 = reinterpret_cast<const NodeMeta*>(rec5 + (size_t)PG * (n - D0 + 1));
+                        const double rhs5 = rec5[(size_t)(n - D0) * PG + gl];
+                        if (pivot_from_record<S5>(rec5, n - D0, rhs5, used5, a - D0, m, gl, gbase, pm5->minp,
+                                                  pm5->maxp, R4, rhs4, used4, minp4, maxp4)) {
                             have4 = true;
                             a4 = a;
                             rb4 = rb5;
@@ -435,8 +440,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                     const unsigned long long cnt = binom(d, n - 1 - a, 3);
                     const unsigned long long ov = overlap(rb4, cnt, begin, end);
                     if (ov != 0ULL) {
-                        if (pivot_level<S4>(R4, rhs4, used4, a - (D0 + 1), m, gl, gbase, minp4, maxp4, R3,
-                                            rhs3, used3, minp3, maxp3)) {
+                        const double w4 = select_slot<S4>(R4, a - (D0 + 1));
+                        double big4;
+                        const int p4 = pick_pivot_row(w4, used4, gbase, big4);
+                        minp3 = fmin(minp4, big4);
+                        maxp3 = fmax(maxp4, big4);
+                        if ((big4 > 0.0) && !(minp3 <= DBL_EPSILON * (double)m * maxp3)) {
+                            addr4 = (gbase + p4) << 2;
+                            const double inv4 = 1.0 / bcast16(w4, addr4);
+                            isp4 = (gl == p4);
+                            lx4 = isp4 ? inv4 : -(w4 * inv4);
+                            rhs3 = fma(lx4, bcast16(rhs4, addr4), isp4 ? -0.0 : rhs4);
+                            used3 = used4 || isp4;
                             have3 = true;
                             a3 = a;
                             rb3 = rb4;
@@ -468,7 +483,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                 rb3 += cnt;
                 if (ov == 0ULL) continue;
                 const int ka = a - (D0 + 2);
-                const double w = select_slot<S3>(R3, ka);
+                // column a of the depth m-3 node = one fma on R4's column a (R3 slot ka = R4 slot ka+1)
+                const double w4c = select_slot<S4>(R4, ka + 1);
+                const double w = fma(lx4, bcast16(w4c, addr4), isp4 ? -0.0 : w4c);
                 double big;
                 const int p = pick_pivot_row(w, used3, gbase, big);
                 const double minp = fmin(minp3, big), maxp = fmax(maxp3, big);
@@ -491,8 +508,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
                         for (int j = 0; j < 4; ++j) {
                             const int k = kb + j;
                             if (k < S3) {
-                                const double pc = bcast16(R3[k], addr);
-                                v[j] = fma(lx, pc, isp ? -0.0 : R3[k]);
+                                const double r4 = R4[k + 1];
+                                const double r3 = fma(lx4, bcast16(r4, addr4), isp4 ? -0.0 : r4);
+                                const double pc = bcast16(r3, addr);
+                                v[j] = fma(lx, pc, isp ? -0.0 : r3);
                             }
                         }
 #pragma unroll
@@ -593,10 +612,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_enum_sweep(EnumDev d, PrefixD
         if (!__syncthreads_or(active || have3)) break;
     }
     // ---------------- counts: block-level first, then one device atomic per counter
-    if (gl == 0) cntS += cntSg;
-    if (cntF) atomicAdd(&s_cnt[0], cntF);
-    if (cntI) atomicAdd(&s_cnt[1], cntI);
-    if (cntS) atomicAdd(&s_cnt[2], cntS);
+    if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
+    if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
+    if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
+    if (gl == 0 && cntSg) atomicAdd(&s_cnt[2], cntSg);
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
 }
@@ -680,9 +699,9 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         if (count == 0) break;
     }
     if (count > 0) {
-        // one workgroup per CU (the kernel's registers allow one resident workgroup per CU); roots
-        // are dealt round-robin to the grid's groups
-        const int grid = std::min(lp_ceil_div(count, SWEEP_GROUPS), ctx->num_cus);
+        // two workgroups per CU are resident (<= 256 VGPRs, 52 KB LDS each); a few more than that so
+        // that the tail is filled by the dynamic root dealing
+        const int grid = std::min(lp_ceil_div(count, SWEEP_GROUPS), ctx->num_cus * 4);
         hipLaunchKernelGGL(k_enum_sweep, grid, SWEEP_THREADS, 0, s, d, pd,
                            p->prefix_buf[cur], count, (unsigned long long)begin, (unsigned long long)end);
         ++launches;
