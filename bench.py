@@ -52,6 +52,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/): bench.py cannot
+    run rocprofv3 on itself; the collection recipe is in profiles/README.md."""
+    try:
+        data = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_update_traffic.json")))
+        return float(data[kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def pivot_leg(ctx, args):
     """Simplex on the m=512 x n=1024 random LP (BASELINE configs[1]).
 
@@ -100,6 +110,7 @@ def pivot_leg(ctx, args):
         "whole_solve_equiv_GBs": round(bytes_per_pivot * pivots / (best["solve_ms"] * 1e-3) / 1e9, 1),
         "rank1_update_us_per_launch": round(1e3 * upd1_ms, 3),
         "rank1_update_GBs": round(bytes_per_pivot / (upd1_ms * 1e-3) / 1e9, 1),
+        "rank1_update_traffic_bytes": pmc_traffic("k_simplex_update") if (m, n) == (512, 1024) else None,
     }
     if best["update_launches"] > 0 and best["update_ms"] > 0:
         out["update_launch_us_inside_solve_event_bracketed"] = round(
@@ -111,7 +122,8 @@ def pivot_leg(ctx, args):
             "kernel": "k_look_update (rank-J Gauss-Jordan update: J staged pivots applied in one "
                       "pass over the tableau)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic("k_look_update") if (m, n) == (512, 1024) else None,
             "launches": 200,
             "avg_launch_us": round(1e3 * per_launch_ms, 3),
             "pivots_per_launch": int(pivots_per_launch),
@@ -127,7 +139,8 @@ def pivot_leg(ctx, args):
         roofline = {
             "kernel": "k_simplex_update (rank-1 Gauss-Jordan update, one launch per pivot)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic("k_simplex_update") if (m, n) == (512, 1024) else None,
             "algorithmic_bytes_per_launch": bytes_per_pivot,
         }
     return out, roofline
