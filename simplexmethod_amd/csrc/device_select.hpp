@@ -60,9 +60,11 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 template <bool WANT_MAX>
 __device__ __forceinline__ double wave_ext_f64(double v) {
     double o;
+    // v_max_f64 / v_min_f64: one instruction per step (inputs are never NaN here: ineligible
+    // entries were replaced by the +-inf sentinel before the reduction)
 #define LP_STEP(CTRL, MASK)                              \
     o = dpp_f64<CTRL, MASK>(v);                          \
-    v = WANT_MAX ? (o > v ? o : v) : (o < v ? o : v);
+    v = WANT_MAX ? fmax(v, o) : fmin(v, o);
     LP_STEP(LP_DPP_QUAD_XOR1, 0xF)
     LP_STEP(LP_DPP_QUAD_XOR2, 0xF)
     LP_STEP(LP_DPP_ROW_HALF_MIRROR, 0xF)
@@ -74,6 +76,21 @@ __device__ __forceinline__ double wave_ext_f64(double v) {
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), 63);
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Extreme over each 16-lane DPP row (4 steps), valid in every lane of the row.
+template <bool WANT_MAX>
+__device__ __forceinline__ double row16_ext_f64(double v) {
+    double o;
+#define LP_STEP(CTRL)                    \
+    o = dpp_f64<CTRL, 0xF>(v);           \
+    v = WANT_MAX ? fmax(v, o) : fmin(v, o);
+    LP_STEP(LP_DPP_QUAD_XOR1)
+    LP_STEP(LP_DPP_QUAD_XOR2)
+    LP_STEP(LP_DPP_ROW_HALF_MIRROR)
+    LP_STEP(LP_DPP_ROW_MIRROR)
+#undef LP_STEP
+    return v;
 }
 
 __device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
@@ -220,7 +237,7 @@ __device__ int block_chain_select(const double* vals, const unsigned char* mask,
         const double Ml = has ? sc->M[lane] : sentinel;
         const double Pl = has ? sc->P[lane] : sentinel;
         const int Jl = has ? sc->J[lane] : INT_MAX;
-        const double M = wave_ext_f64<WANT_MAX>(Ml);
+        const double M = wave_bcast_f64(row16_ext_f64<WANT_MAX>(Ml), 0);
         const unsigned long long whit = __ballot(has && Ml == M && Jl != INT_MAX);
         int sel = -1;
         double best = sentinel;
@@ -229,7 +246,7 @@ __device__ int block_chain_select(const double* vals, const unsigned char* mask,
             const int W = (int)__builtin_ctzll(whit);
             const int jM = __builtin_amdgcn_readlane(Jl, W);
             const double Pin = wave_bcast_f64(Pl, W);
-            const double Pprev = wave_ext_f64<WANT_MAX>((lane < W) ? Ml : sentinel);
+            const double Pprev = wave_bcast_f64(row16_ext_f64<WANT_MAX>((lane < W) ? Ml : sentinel), 0);
             const double P = ext2<WANT_MAX>(Pprev, Pin);
             if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
                 best = M;

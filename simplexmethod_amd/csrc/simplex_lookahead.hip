@@ -1,5 +1,6 @@
 // simplex_lookahead.hip — single-LP tableau simplex with J-pivot look-ahead
-// (LP_SIMPLEX_ALGO_PERSISTENT's successor; selected by LP_SIMPLEX_ALGO_AUTO).
+// (LP_SIMPLEX_ALGO_LOOKAHEAD; what LP_SIMPLEX_ALGO_AUTO selects whenever the selector's
+// working set fits one CU's LDS).
 //
 // Same pivot rules as simplex_launch.hip (/root/reference/src/SimplexSolover.h:152-196)
 // and bit-identical tableau values, but the 4.2 MB tableau is read and written once per
@@ -25,7 +26,10 @@
 namespace {
 
 constexpr int kRunning = -100;
-constexpr int SEL_THREADS = 1024;
+#ifndef LP_SEL_THREADS
+#define LP_SEL_THREADS 1024
+#endif
+constexpr int SEL_THREADS = LP_SEL_THREADS;
 
 // LDS carve of the selector (all in the dynamic region, 16-B aligned pieces)
 struct QInfo {   // one staged pivot, read with a single 16-B LDS load
@@ -248,13 +252,14 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
 // to its LU_RPT rows x one 16-B column pair in registers.
 constexpr int LU_TX = 64;    // column pairs per block (128 columns)
 constexpr int LU_TY = 4;
-constexpr int LU_RPT = 4;    // rows per thread
+#ifndef LP_LU_RPT
+#define LP_LU_RPT 4
+#endif
+constexpr int LU_RPT = LP_LU_RPT;    // rows per thread
 constexpr int LU_ROWS = LU_TY * LU_RPT;  // 16 rows per block
 constexpr int LU_JMAX = 16;  // upper bound of LookDev::J
 
 __global__ __launch_bounds__(LU_TX* LU_TY) void k_look_update(SimplexDev d, LookDev la) {
-    const int count = *la.count;
-    if (count == 0) return;
     __shared__ __attribute__((aligned(16))) double s_pr[LU_JMAX][2 * LU_TX];
     __shared__ double s_l[LU_JMAX][LU_ROWS];
     __shared__ int s_piv[2 * LU_JMAX];
@@ -263,24 +268,31 @@ __global__ __launch_bounds__(LU_TX* LU_TY) void k_look_update(SimplexDev d, Look
     const int tid = threadIdx.y * LU_TX + threadIdx.x;
     const int col0 = blockIdx.x * 2 * LU_TX;   // first column of the tile
     const int row0 = blockIdx.y * LU_ROWS;
-    for (int k = tid; k < count * 2 * LU_TX; k += LU_TX * LU_TY) {
-        const int q = k / (2 * LU_TX), j = k - q * 2 * LU_TX;
-        s_pr[q][j] = (col0 + j < d.ld) ? la.etaP[(size_t)q * d.ld + col0 + j] : 0.0;
-    }
-    for (int k = tid; k < count * LU_ROWS; k += LU_TX * LU_TY) {
-        const int q = k / LU_ROWS, i = k - q * LU_ROWS;
-        s_l[q][i] = (row0 + i < rows) ? la.etaL[(size_t)q * la.rows_pad + row0 + i] : 0.0;
-    }
-    if (tid < 2 * count) s_piv[tid] = la.piv[tid];
     const int jp = blockIdx.x * LU_TX + threadIdx.x;
     const bool live = jp < ld2;
     const int i0 = row0 + threadIdx.y * LU_RPT;
     double2* T2 = reinterpret_cast<double2*>(d.T);
+    // Everything below is issued before the staged-pivot count is known, so that the count, the
+    // tile and the eta operands are all in flight together (one memory round trip, not three);
+    // the whole J-slot eta buffer is staged, entries beyond `count` are simply not used.
     double2 t[LU_RPT];
 #pragma unroll
     for (int k = 0; k < LU_RPT; ++k)
         t[k] = (live && i0 + k < rows) ? T2[(size_t)(i0 + k) * ld2 + jp] : make_double2(0.0, 0.0);
+    const int J = la.J;
+    for (int k = tid; k < J * 2 * LU_TX; k += LU_TX * LU_TY) {
+        const int q = k / (2 * LU_TX), j = k - q * 2 * LU_TX;
+        s_pr[q][j] = (col0 + j < d.ld) ? la.etaP[(size_t)q * d.ld + col0 + j] : 0.0;
+    }
+    for (int k = tid; k < J * LU_ROWS; k += LU_TX * LU_TY) {
+        const int q = k / LU_ROWS, i = k - q * LU_ROWS;
+        s_l[q][i] = (row0 + i < rows) ? la.etaL[(size_t)q * la.rows_pad + row0 + i] : 0.0;
+    }
+    if (tid < 2 * J) s_piv[tid] = la.piv[tid];
+    const int count = *la.count;
+    if (count == 0) return;  // block-uniform
     __syncthreads();
+#pragma unroll 4
     for (int q = 0; q < count; ++q) {
         const int e = s_piv[2 * q], r = s_piv[2 * q + 1];
         const int je = e >> 1;

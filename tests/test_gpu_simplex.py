@@ -168,3 +168,24 @@ def test_golden_vectors_gpu(ctx):
         assert g["basis"].tolist() == case["basis"] and g["obj"] == case["obj"]
         for j, v in case["x_nonzero"].items():
             assert g["x"][int(j)] == v
+
+
+def test_update_microbenchmarks_and_profiling(ctx):
+    """The measurement hooks bench.py uses leave the problem intact."""
+    A, b, c, basis = lpcases.random_lp(3, 64, 160)
+    r = o.simplex_tableau(A, b, c, basis, True, 96)
+    p = ctx.simplex_problem(A, b, c, basis, True, 96)
+    ms1 = p.bench_update(0, 0, 20)
+    msj, j = p.bench_update_rankj(20)
+    assert ms1 > 0 and msj > 0 and 1 <= j <= 16
+    p.reset()
+    p.profile(True)
+    rc, st = p.run(algo=capi.SIMPLEX_LOOKAHEAD)
+    assert rc == 0 and st.update_launches > 0 and st.update_ms > 0
+    p.profile(False)
+    d = p.download()
+    assert st.pivots == r["iters"] and np.array_equal(d["x"], r["x"]) and np.array_equal(d["basis"], r["basis"])
+    p.reset()
+    rc, st = p.run(algo=capi.SIMPLEX_LOOKAHEAD)
+    assert st.update_launches == 0 and st.pivots == r["iters"]
+    p.free()
