@@ -1,0 +1,251 @@
+// enum_leaf.hip — leaf kernel of the shared-prefix enumeration: ONE LANE PER SUBSET.
+//
+// Input: the depth D = m-6 records produced breadth-first by k_enum_expand (enum_prefix.hip):
+// the tableau [W[:, c > last] | rhs] after the first m-6 Gauss-Jordan steps, shared by every
+// subset with that prefix.  A wave owns one record at a time, copies its live columns to its
+// private LDS slice, and each of its 64 lanes then finishes one subset on its own: it picks
+// the remaining KD = 6 columns (lexicographic unranking of its leaf index), replays the last
+// four Gauss-Jordan steps and the 2x2 block exactly as oracle/lp_oracle.c: orc_enum_subset
+// orders them, and tests feasibility.  No cross-lane traffic, no barriers, no divergence
+// beyond the leaf loop's tail: the ~900 instructions per subset are ordinary lane-parallel
+// fp64 work, which is what this chip has in abundance (the cooperative sweep of
+// enum_prefix.hip shares two more levels but is bound by the latency of its broadcasts,
+// pivot searches and workgroup barriers).
+//
+//   phase 1  the 6 rows not used by the prefix x the 6 chosen columns (+ rhs) sit in
+//            registers; 4 Gauss-Jordan steps with partial pivoting among the unused rows
+//            (pivot row = select chain over 6), then the 2x2 block -> x_a, x_b.
+//   phase 2  each of the m-6 rows used by the prefix streams through: 7 LDS reads, the same
+//            4 eliminations against the stored pivot rows, back-substitution, x >= -1e-9.
+#include "enum_tree.hpp"
+
+using namespace lptree;
+
+namespace {
+
+constexpr int KD = 6;                 // columns chosen per lane
+constexpr int LEAF_THREADS = 256;
+constexpr int LEAF_WAVES = LEAF_THREADS / 64;
+constexpr int MAXCOLS = NMX + KD + 1;  // live columns of a depth m-6 record (+ rhs)
+
+__device__ __forceinline__ double sel6(int r, double a0, double a1, double a2, double a3, double a4,
+                                       double a5) {
+    double v = a0;
+    v = (r == 1) ? a1 : v;
+    v = (r == 2) ? a2 : v;
+    v = (r == 3) ? a3 : v;
+    v = (r == 4) ? a4 : v;
+    v = (r == 5) ? a5 : v;
+    return v;
+}
+
+__global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixDev pd,
+                                                              const double* __restrict__ roots,
+                                                              int nroots, int chunks,
+                                                              unsigned long long begin,
+                                                              unsigned long long end) {
+    __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES][MAXCOLS * PG];
+    __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= 23, k <= 6
+    __shared__ unsigned long long s_cnt[3];
+
+    const int m = d.m, n = d.n, D = m - KD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
+        const int r = k / (KD + 1), kk = k - r * (KD + 1);
+        s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
+    }
+    if (tid < 3) s_cnt[tid] = 0ULL;
+    __syncthreads();
+    double* tab = s_tab[wave];
+    unsigned int cntF = 0, cntI = 0, cntS = 0;
+
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(pd.root_cursor, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        // work item = (record, chunk of its leaves); chunks > 1 only when there are too few
+        // records to occupy the chip (shallow trees)
+        if (idx >= nroots * chunks) break;
+        const int chunk = idx % chunks;
+        idx /= chunks;
+        const double* P = roots + (size_t)idx * rec_doubles(n, D);
+        const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D + 1));
+        if (pm.last_col == kHole) continue;
+        const int R = n - 1 - pm.last_col;           // selectable columns
+        if (R < KD) continue;
+        const int first = pm.last_col + 1 - D;       // record slot of the first live column
+        // live columns + rhs -> this wave's LDS slice (column q of the slice = column last+1+q)
+        for (int k = lane; k < (R + 1) * PG; k += 64) tab[k] = P[(size_t)first * PG + k];
+        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, 6) leaves below this node
+        // rows: the 6 not used by the prefix (ascending), and the used ones
+        const unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
+        int U[KD];
+        {
+            unsigned free_rows = ~umask & ((1u << m) - 1u);
+#pragma unroll
+            for (int r = 0; r < KD; ++r) {
+                U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
+                free_rows &= free_rows - 1u;
+            }
+        }
+        const double minp0 = pm.minp, maxp0 = pm.maxp;
+        const unsigned long long rb = pm.rank_base;
+
+        const unsigned int per = (L + chunks - 1) / chunks;
+        const unsigned int leaf_lo = chunk * per;
+        const unsigned int leaf_hi = (leaf_lo + per < L) ? leaf_lo + per : L;
+        for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
+            const unsigned long long rank = rb + leaf;
+            if (rank < begin || rank >= end) continue;
+            // ---- lexicographic unranking of `leaf` among the 6-subsets of the R live columns
+            int c[KD];
+            {
+                unsigned int rem = leaf;
+                int a = 0;
+#pragma unroll
+                for (int t = 0; t < KD; ++t) {
+                    int j = a;
+                    for (;; ++j) {
+                        const unsigned int cnt = s_binom[(R - 1 - j) * (KD + 1) + (KD - 1 - t)];
+                        if (rem < cnt) break;
+                        rem -= cnt;
+                    }
+                    c[t] = j;
+                    a = j + 1;
+                }
+            }
+            // ---- phase 1: unused rows x chosen columns
+            double E[KD][KD], H[KD];
+#pragma unroll
+            for (int r = 0; r < KD; ++r) {
+#pragma unroll
+                for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * PG + U[r]];
+                H[r] = tab[R * PG + U[r]];
+            }
+            double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
+            double minp = minp0, maxp = maxp0;
+            bool sing = false;
+            unsigned used6 = 0u;
+#pragma unroll
+            for (int t = 0; t < KD - 2; ++t) {
+                // first unused row (ascending row order) of largest |entry|
+                double big = -1.0, piv = 0.0;
+                int p = 0;
+#pragma unroll
+                for (int r = 0; r < KD; ++r) {
+                    const double a = fabs(E[r][t]);
+                    const bool take = !((used6 >> r) & 1u) && (a > big);
+                    big = take ? a : big;
+                    piv = take ? E[r][t] : piv;
+                    p = take ? r : p;
+                }
+                if (!(big > 0.0)) sing = true;
+                minp = fmin(minp, big);
+                maxp = fmax(maxp, big);
+                const double inv = 1.0 / piv;
+                INV[t] = inv;
+#pragma unroll
+                for (int cc = t + 1; cc < KD; ++cc)
+                    PR[t][cc] = sel6(p, E[0][cc], E[1][cc], E[2][cc], E[3][cc], E[4][cc], E[5][cc]);
+                PRH[t] = sel6(p, H[0], H[1], H[2], H[3], H[4], H[5]);
+#pragma unroll
+                for (int r = 0; r < KD; ++r) {
+                    const bool isp = (r == p);
+                    const double lx = isp ? inv : -(E[r][t] * inv);
+#pragma unroll
+                    for (int cc = t + 1; cc < KD; ++cc)
+                        E[r][cc] = fma(lx, PR[t][cc], isp ? -0.0 : E[r][cc]);
+                    H[r] = fma(lx, PRH[t], isp ? -0.0 : H[r]);
+                }
+                used6 |= 1u << p;
+            }
+            // ---- 2x2 block on the two rows still unused (ascending) and columns c[4], c[5]
+            int r1 = 0, r2 = 0;
+            {
+                unsigned fr = ~used6 & 0x3Fu;
+                r1 = fr ? __builtin_ctz(fr) : 0;
+                fr &= fr - 1u;
+                r2 = fr ? __builtin_ctz(fr) : r1;
+            }
+            const double a1 = sel6(r1, E[0][4], E[1][4], E[2][4], E[3][4], E[4][4], E[5][4]);
+            const double a2 = sel6(r2, E[0][4], E[1][4], E[2][4], E[3][4], E[4][4], E[5][4]);
+            const double b1 = sel6(r1, E[0][5], E[1][5], E[2][5], E[3][5], E[4][5], E[5][5]);
+            const double b2 = sel6(r2, E[0][5], E[1][5], E[2][5], E[3][5], E[4][5], E[5][5]);
+            const double h1 = sel6(r1, H[0], H[1], H[2], H[3], H[4], H[5]);
+            const double h2 = sel6(r2, H[0], H[1], H[2], H[3], H[4], H[5]);
+            const bool second = fabs(a2) > fabs(a1);
+            const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
+            const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
+            const double big1 = fabs(pa);
+            const double inv1 = 1.0 / pa;
+            const double l = -(qa * inv1);
+            const double wqb = fma(l, pb, qb);
+            const double rq = fma(l, ph, qh);
+            const double big2 = fabs(wqb);
+            const double inv2 = 1.0 / wqb;
+            const double xb = rq * inv2;
+            const double xa = fma(-pb, xb, ph) * inv1;
+            if (!(big1 > 0.0) || !(big2 > 0.0)) sing = true;
+            minp = fmin(minp, fmin(big1, big2));
+            maxp = fmax(maxp, fmax(big1, big2));
+            if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
+            bool feas = (xa >= -1e-9) && (xb >= -1e-9);
+            // the four rows pivoted in phase 1: back-substitution
+#pragma unroll
+            for (int r = 0; r < KD; ++r) {
+                const double x = fma(-E[r][5], xb, fma(-E[r][4], xa, H[r]));
+                if ((used6 >> r) & 1u) feas = feas && (x >= -1e-9);
+            }
+            // ---- phase 2: rows already used by the prefix, one at a time
+            if (!sing && feas) {
+                unsigned rows = umask & ((1u << m) - 1u);
+                while (rows) {
+                    const int i = __builtin_ctz(rows);
+                    rows &= rows - 1u;
+                    double v[KD];
+#pragma unroll
+                    for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * PG + i];
+                    double h = tab[R * PG + i];
+#pragma unroll
+                    for (int t = 0; t < KD - 2; ++t) {
+                        const double lx = -(v[t] * INV[t]);
+#pragma unroll
+                        for (int cc = t + 1; cc < KD; ++cc) v[cc] = fma(lx, PR[t][cc], v[cc]);
+                        h = fma(lx, PRH[t], h);
+                    }
+                    const double x = fma(-v[5], xb, fma(-v[4], xa, h));
+                    feas = feas && (x >= -1e-9);
+                }
+            }
+            if (sing) {
+                ++cntS;
+            } else if (!feas) {
+                ++cntI;
+            } else {
+                ++cntF;
+                const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                if (at < pd.list_cap) pd.list[at] = rank;
+            }
+        }
+    }
+    if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
+    if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
+    if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
+    __syncthreads();
+    if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
+}
+
+}  // namespace
+
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots, uint64_t begin,
+                          uint64_t end) {
+    lp_context* ctx = p->ctx;
+    // at least ~16 work items per wave slot of the chip
+    const long long want = (long long)ctx->num_cus * 8 * LEAF_WAVES * 16;
+    int chunks = (int)std::min<long long>(64, std::max<long long>(1, want / std::max(nroots, 1)));
+    const long long items = (long long)nroots * chunks;
+    const int grid = (int)std::min<long long>(lp_ceil_div<long long>(items, LEAF_WAVES), (long long)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, p->prefix, roots, nroots,
+                       chunks, (unsigned long long)begin, (unsigned long long)end);
+    return LP_OPTIMAL;
+}

@@ -27,78 +27,17 @@
 #include <cstdlib>
 
 #include "enum_problem.hpp"
+#include "enum_tree.hpp"
 
 namespace {
 
-constexpr int PG = 16;            // lanes per group = max rows
-constexpr int NMX = 16;           // max n - m on this path
-constexpr int META = 8;           // doubles of metadata behind each node record
+using namespace lptree;
+
 constexpr int POOLC = 20;         // LDS columns (16 doubles each) per group for mu tableaus
 constexpr int MAXMU = 10;         // mu descriptors per group per round
 constexpr int SWEEP_THREADS = 256;
 constexpr int SWEEP_GROUPS = SWEEP_THREADS / PG;
-constexpr int PAIRCAP = 3072;
-constexpr int kHole = -2;         // NodeMeta::last_col of a slot whose subtree was pruned     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
-
-struct NodeMeta {  // 64 bytes, stored behind the columns of a record
-    unsigned long long rank_base;  // rank of the first subset below this node
-    double minp, maxp;             // smallest / largest |pivot| so far
-    int last_col;                  // last chosen column (-1 at the root)
-    unsigned used_mask;            // bit i: row i already used as a pivot row
-    int pad[8];
-};
-static_assert(sizeof(NodeMeta) == META * 8, "NodeMeta must be 64 bytes");
-
-__device__ __forceinline__ size_t rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
-
-__device__ __forceinline__ unsigned long long binom(const EnumDev& d, int nn, int kk) {
-    if (kk < 0 || nn < kk || nn < 0) return 0ULL;
-    return d.binom[nn * kBinomK + kk];
-}
-
-__device__ __forceinline__ unsigned long long overlap(unsigned long long rb, unsigned long long cnt,
-                                                      unsigned long long begin, unsigned long long end) {
-    const unsigned long long lo = rb > begin ? rb : begin;
-    const unsigned long long hi = (rb + cnt) < end ? (rb + cnt) : end;
-    return hi > lo ? hi - lo : 0ULL;
-}
-
-// max over the 16 lanes of a group (DPP row operations), result in every lane of the group
-__device__ __forceinline__ double row_max_f64(double v) {
-    double o;
-#define LP_RSTEP(CTRL)                                                                   \
-    {                                                                                    \
-        const long long b = __double_as_longlong(v);                                     \
-        int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);                           \
-        lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);                 \
-        hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);                 \
-        o = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);              \
-        v = fmax(v, o);                                                                  \
-    }
-    LP_RSTEP(0xB1)   // quad_perm [1,0,3,2]
-    LP_RSTEP(0x4E)   // quad_perm [2,3,0,1]
-    LP_RSTEP(0x141)  // row_half_mirror
-    LP_RSTEP(0x140)  // row_mirror
-#undef LP_RSTEP
-    return v;
-}
-
-// Broadcast of lane (gbase + p)'s value to its group: addr = (gbase + p) << 2, computed once per pivot.
-__device__ __forceinline__ double bcast16(double v, int addr) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xFFFFFFFFLL));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Partial-pivot row choice for one group: first unused row of largest |w| (strict > keeps the
-// first).  Returns the group-relative lane p and big = |w_p| (big = -1 if no unused row).
-__device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, double& big) {
-    const double a = used ? -1.0 : fabs(w);
-    big = row_max_f64(a);
-    const unsigned long long hit = (__ballot(a == big && !used) >> gbase) & 0xFFFFULL;
-    return hit ? (int)__builtin_ctzll(hit) : 0;
-}
+constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
 
 // ---------------------------------------------------------------------------
 // phase 1: expand level t -> t+1 (records in HBM)
@@ -630,7 +569,7 @@ static size_t host_rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) +
 
 bool lp_enum_prefix_supported(const lp_enum_problem* p) {
     const EnumDev& d = p->dev;
-    return d.m >= 6 && d.m <= PG && (d.n - d.m) <= NMX && (d.n - d.m) >= 2;
+    return d.m >= 6 && d.m <= PG && (d.n - d.m) <= NMX && (d.n - d.m) >= 2;  // m - 6 >= 0 levels
 }
 
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
@@ -638,12 +577,17 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     lp_context* ctx = p->ctx;
     const EnumDev& d = p->dev;
     hipStream_t s = ctx->stream;
-    const int m = d.m, n = d.n, D0 = m - 5;
+    const int m = d.m, n = d.n;
+    // default: breadth-first to depth m-6, then one lane per subset (enum_leaf.hip);
+    // LP_ENUM_SWEEP=1 selects the cooperative register-resident sweep from depth m-5 instead
+    const bool use_leaf = getenv("LP_ENUM_SWEEP") == nullptr;
+    const int D0 = use_leaf ? m - 6 : m - 5;
     PrefixDev& pd = p->prefix;
     // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0)
     const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
     const size_t need = (size_t)nodes_max * host_rec_doubles(n, D0) * sizeof(double);
-    const size_t need_prev = (size_t)lp_host_binom(n - m + D0 - 1, D0 - 1) * host_rec_doubles(n, D0 - 1) * sizeof(double);
+    const size_t need_prev = D0 >= 1 ? (size_t)lp_host_binom(n - m + D0 - 1, D0 - 1) * host_rec_doubles(n, D0 - 1) * sizeof(double)
+                                     : (size_t)host_rec_doubles(n, 0) * sizeof(double);
     if (p->prefix_buf_bytes[0] < need) {
         if (p->prefix_buf[0]) (void)hipFree(p->prefix_buf[0]);
         p->prefix_buf[0] = nullptr;
@@ -698,7 +642,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         cur = nxt;
         if (count == 0) break;
     }
-    if (count > 0) {
+    if (count > 0 && use_leaf) {
+        lp_enum_launch_leaves(p, p->prefix_buf[cur], count, begin, end);
+        ++launches;
+    } else if (count > 0) {
         // two workgroups per CU are resident (<= 256 VGPRs, 52 KB LDS each); a few more than that so
         // that the tail is filled by the dynamic root dealing
         const int grid = std::min(lp_ceil_div(count, SWEEP_GROUPS), ctx->num_cus * 4);

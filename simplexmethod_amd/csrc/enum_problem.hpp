@@ -105,6 +105,10 @@ int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 // smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
 
+// enum_leaf.hip: one lane per subset below the depth m-6 records
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots, uint64_t begin,
+                          uint64_t end);
+
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
 // LP_ITER_LIMIT = "could not run here (memory / list overflow), use the direct path"
