@@ -393,7 +393,7 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_count); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
     if (p->h_level_count) (void)hipHostFree(p->h_level_count);
     if (p->h_list_count) (void)hipHostFree(p->h_list_count);
@@ -476,6 +476,26 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipMemcpyAsync(p->dpairtab, pairtab.data(), sizeof(unsigned short) * pairtab.size(),
                               hipMemcpyHostToDevice, s));
         pd.pairtab = p->dpairtab;
+        // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
+        std::vector<unsigned> comb6(32, 0u);
+        for (int R = 6; R <= 22; ++R) {
+            comb6[(size_t)R] = (unsigned)comb6.size();
+            int s6[6] = {0, 1, 2, 3, 4, 5};
+            for (;;) {
+                unsigned pk = 0;
+                for (int t = 0; t < 6; ++t) pk |= (unsigned)s6[t] << (5 * t);
+                comb6.push_back(pk);
+                int t = 5;
+                while (t >= 0 && s6[t] == R - 6 + t) --t;
+                if (t < 0) break;
+                ++s6[t];
+                for (int u = t + 1; u < 6; ++u) s6[u] = s6[u - 1] + 1;
+            }
+        }
+        LP_TRY(hipMalloc(&p->dcomb6, sizeof(unsigned) * comb6.size()));
+        LP_TRY(hipMemcpyAsync(p->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
+        LP_TRY(hipStreamSynchronize(s));  // comb6 is a local
+        pd.comb6 = p->dcomb6;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

@@ -27,6 +27,8 @@ constexpr int KD = 6;                 // columns chosen per lane
 constexpr int LEAF_THREADS = 256;
 constexpr int LEAF_WAVES = LEAF_THREADS / 64;
 constexpr int MAXCOLS = NMX + KD + 1;  // live columns of a depth m-6 record (+ rhs)
+constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
+                                      // same row of different columns hit different banks
 
 __device__ __forceinline__ double sel6(int r, double a0, double a1, double a2, double a3, double a4,
                                        double a5) {
@@ -44,9 +46,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                                                               int nroots, int chunks,
                                                               unsigned long long begin,
                                                               unsigned long long end) {
-    __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES][MAXCOLS * PG];
+    __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= 23, k <= 6
     __shared__ unsigned long long s_cnt[3];
+    __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
     const int m = d.m, n = d.n, D = m - KD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,28 +58,69 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
+    if (tid < 32) s_off[tid] = pd.comb6[tid];
     __syncthreads();
-    double* tab = s_tab[wave];
     unsigned int cntF = 0, cntI = 0, cntS = 0;
 
+    // Software pipeline over work items (record, chunk): while item A is computed from LDS slice
+    // `buf`, the whole record of item B (its index was drawn one iteration earlier) is in flight
+    // into registers, and the index of item C is being drawn — neither the atomic nor the HBM
+    // round trip of a record sits between two items.
+    constexpr int NLOAD = (MAXCOLS * PG + 63) / 64;   // doubles per lane to hold one record
+    const int rec_cols = n - D + 1;                   // columns of a record incl. rhs
+    const long long nitems = (long long)nroots * chunks;
+    // items are drawn kDraw at a time: one returning atomic on a single word costs ~11 ns chip-wide,
+    // which at one draw per record (5.3 M records for C(32,16)) would bound the whole kernel
+    constexpr int kDraw = 16;
+    int draw_next = 0, draw_end = 0;
+    auto draw = [&]() {
+        if (draw_next == draw_end) {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(pd.root_cursor, kDraw);
+            draw_next = __builtin_amdgcn_readfirstlane(v);
+            draw_end = draw_next + kDraw;
+        }
+        return draw_next++;
+    };
+    double pre[NLOAD];
+    NodeMeta pmB;
+    auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
+        const int node = item / chunks;
+        const double* Q = roots + (size_t)node * rec_doubles(n, D);
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const int k = lane + 64 * q;
+            pre[q] = (k < rec_cols * PG) ? Q[k] : 0.0;
+        }
+        pmB = *reinterpret_cast<const NodeMeta*>(Q + (size_t)PG * rec_cols);
+    };
+    int itemB = draw();
+    int itemC = draw();
+    if (itemB < nitems) fetch(itemB);
+    int buf = 0;
     for (;;) {
-        int idx = 0;
-        if (lane == 0) idx = atomicAdd(pd.root_cursor, 1);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        // work item = (record, chunk of its leaves); chunks > 1 only when there are too few
-        // records to occupy the chip (shallow trees)
-        if (idx >= nroots * chunks) break;
-        const int chunk = idx % chunks;
-        idx /= chunks;
-        const double* P = roots + (size_t)idx * rec_doubles(n, D);
-        const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D + 1));
+        if (itemB >= nitems) break;
+        // ---- item B becomes the current item: registers -> LDS slice (odd column stride)
+        const int item = itemB;
+        const NodeMeta pm = pmB;
+        double* tab = s_tab[wave * 2 + buf];
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const int k = lane + 64 * q;
+            if (k < rec_cols * PG) tab[(k >> 4) * TS + (k & 15)] = pre[q];
+        }
+        buf ^= 1;
+        itemB = itemC;
+        itemC = draw();
+        if (itemB < nitems) fetch(itemB);
+        const int chunk = item % chunks;
         if (pm.last_col == kHole) continue;
         const int R = n - 1 - pm.last_col;           // selectable columns
         if (R < KD) continue;
-        const int first = pm.last_col + 1 - D;       // record slot of the first live column
-        // live columns + rhs -> this wave's LDS slice (column q of the slice = column last+1+q)
-        for (int k = lane; k < (R + 1) * PG; k += 64) tab[k] = P[(size_t)first * PG + k];
+        const int first = pm.last_col + 1 - D;       // slice column of the first live column
+        tab += first * TS;                           // column q below = column last+1+q
         const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, 6) leaves below this node
+        const unsigned* comb = pd.comb6 + s_off[R];
         // rows: the 6 not used by the prefix (ascending), and the used ones
         const unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
         int U[KD];
@@ -97,30 +141,21 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
             if (rank < begin || rank >= end) continue;
-            // ---- lexicographic unranking of `leaf` among the 6-subsets of the R live columns
+            // ---- the leaf's 6 columns: table of all 6-subsets of R columns in lexicographic order
+            // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
             int c[KD];
             {
-                unsigned int rem = leaf;
-                int a = 0;
+                const unsigned pk = comb[leaf];
 #pragma unroll
-                for (int t = 0; t < KD; ++t) {
-                    int j = a;
-                    for (;; ++j) {
-                        const unsigned int cnt = s_binom[(R - 1 - j) * (KD + 1) + (KD - 1 - t)];
-                        if (rem < cnt) break;
-                        rem -= cnt;
-                    }
-                    c[t] = j;
-                    a = j + 1;
-                }
+                for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
             }
             // ---- phase 1: unused rows x chosen columns
             double E[KD][KD], H[KD];
 #pragma unroll
             for (int r = 0; r < KD; ++r) {
 #pragma unroll
-                for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * PG + U[r]];
-                H[r] = tab[R * PG + U[r]];
+                for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * TS + U[r]];
+                H[r] = tab[R * TS + U[r]];
             }
             double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
             double minp = minp0, maxp = maxp0;
@@ -197,15 +232,18 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                 if ((used6 >> r) & 1u) feas = feas && (x >= -1e-9);
             }
             // ---- phase 2: rows already used by the prefix, one at a time
-            if (!sing && feas) {
+            // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
+            // after a row or two: it stops as soon as no lane of the wave is still feasible)
+            bool alive = !sing && feas;
+            {
                 unsigned rows = umask & ((1u << m) - 1u);
-                while (rows) {
+                while (rows && __any(alive)) {
                     const int i = __builtin_ctz(rows);
                     rows &= rows - 1u;
                     double v[KD];
 #pragma unroll
-                    for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * PG + i];
-                    double h = tab[R * PG + i];
+                    for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * TS + i];
+                    double h = tab[R * TS + i];
 #pragma unroll
                     for (int t = 0; t < KD - 2; ++t) {
                         const double lx = -(v[t] * INV[t]);
@@ -215,6 +253,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                     }
                     const double x = fma(-v[5], xb, fma(-v[4], xa, h));
                     feas = feas && (x >= -1e-9);
+                    alive = alive && feas;
                 }
             }
             if (sing) {

@@ -59,6 +59,8 @@ struct PrefixDev {
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
     const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
+    const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
+                                      // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]
     unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
 };
 
@@ -85,6 +87,7 @@ struct lp_enum_problem {
     double* prefix_buf[2] = {nullptr, nullptr};
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
+    unsigned* dcomb6 = nullptr;
     int* h_level_count = nullptr;              // pinned
     unsigned long long* h_list_count = nullptr;  // pinned
     int* h_overflow = nullptr;                 // pinned
