@@ -391,11 +391,11 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dbinom);
     (void)hipFree(p->dev.result); (void)hipFree(p->dev.chunk_best);
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
-    (void)hipFree(p->prefix.level_count); (void)hipFree(p->prefix.overflow);
+    (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
     (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
-    if (p->h_level_count) (void)hipHostFree(p->h_level_count);
+    if (p->h_level_counts) (void)hipHostFree(p->h_level_counts);
     if (p->h_list_count) (void)hipHostFree(p->h_list_count);
     if (p->h_overflow) (void)hipHostFree(p->h_overflow);
     if (p->h_result) (void)hipHostFree(p->h_result);
@@ -463,14 +463,14 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
             for (int qa = 0; qa < R; ++qa)
                 for (int qb = qa + 1; qb < R; ++qb) pairtab[(size_t)R * kPairTabStride + r++] = (unsigned short)(qa | (qb << 8));
         }
-        LP_TRY(hipMalloc(&pd.level_count, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
         LP_TRY(hipMalloc(&pd.root_cursor, sizeof(int)));
         LP_TRY(hipMalloc(&pd.list, sizeof(unsigned long long) * pd.list_cap));
         LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
         LP_TRY(hipMalloc(&pd.scores, sizeof(double) * pd.list_cap));
         LP_TRY(hipMalloc(&p->dpairtab, sizeof(unsigned short) * pairtab.size()));
-        LP_TRY(hipHostMalloc(&p->h_level_count, sizeof(int)));
+        LP_TRY(hipHostMalloc(&p->h_level_counts, sizeof(int) * 32));
         LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
         LP_TRY(hipHostMalloc(&p->h_overflow, sizeof(int)));
         LP_TRY(hipMemcpyAsync(p->dpairtab, pairtab.data(), sizeof(unsigned short) * pairtab.size(),

@@ -43,7 +43,7 @@ __device__ __forceinline__ double sel6(int r, double a0, double a1, double a2, d
 
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixDev pd,
                                                               const double* __restrict__ roots,
-                                                              int nroots, int chunks,
+                                                              int root_level, int root_cap, int chunks,
                                                               unsigned long long begin,
                                                               unsigned long long end) {
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
@@ -52,6 +52,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
     const int m = d.m, n = d.n, D = m - KD;
+    // device-side count of the depth-D records (clamped to what the buffer can hold)
+    const int nroots = min(pd.level_counts[root_level], root_cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
@@ -276,15 +278,18 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
 
 }  // namespace
 
-int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots, uint64_t begin,
-                          uint64_t end) {
+// nroots_bound: combinatorial upper bound of the record count (the actual count is read on the
+// device from level_counts[root_level]); it only sizes the grid and the chunking.
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots_bound, int root_level,
+                          uint64_t begin, uint64_t end) {
+    const int nroots = nroots_bound;
     lp_context* ctx = p->ctx;
     // at least ~16 work items per wave slot of the chip
     const long long want = (long long)ctx->num_cus * 8 * LEAF_WAVES * 16;
     int chunks = (int)std::min<long long>(64, std::max<long long>(1, want / std::max(nroots, 1)));
     const long long items = (long long)nroots * chunks;
     const int grid = (int)std::min<long long>(lp_ceil_div<long long>(items, LEAF_WAVES), (long long)ctx->num_cus * 8);
-    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, p->prefix, roots, nroots,
-                       chunks, (unsigned long long)begin, (unsigned long long)end);
+    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, p->prefix, roots, root_level,
+                       nroots_bound, chunks, (unsigned long long)begin, (unsigned long long)end);
     return LP_OPTIMAL;
 }

@@ -43,7 +43,7 @@ constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x
 // phase 1: expand level t -> t+1 (records in HBM)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
-                                                     const double* __restrict__ src, int nsrc,
+                                                     const double* __restrict__ src, int src_cap,
                                                      double* __restrict__ dst, int dst_cap,
                                                      unsigned long long begin,
                                                      unsigned long long end) {
@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int gl = threadIdx.x & (PG - 1);
     const int lane = threadIdx.x & 63, gbase = lane & ~(PG - 1);
     const int node = blockIdx.x * (blockDim.x / PG) + (threadIdx.x / PG);
+    // the level's record count lives on the device (level_counts[t]): the host queues all levels
+    // without synchronising, with grids sized for the combinatorial upper bound
+    const int nsrc = min(pd.level_counts[t], src_cap);  // (an overflowed level is reported by the host)
+    if (blockIdx.x * (blockDim.x / PG) >= nsrc) return;  // whole block beyond the level
     const double* P = src + (size_t)(node < nsrc ? node : 0) * rec_doubles(n, t);
     const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
     const bool valid = node < nsrc && pm.last_col != kHole;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int g0 = __shfl(nchild, 0, 64), g1 = __shfl(nchild, 16, 64), g2 = __shfl(nchild, 32, 64),
               g3 = __shfl(nchild, 48, 64);
     int wbase = 0;
-    if (lane == 0 && g0 + g1 + g2 + g3 > 0) wbase = atomicAdd(pd.level_count, g0 + g1 + g2 + g3);
+    if (lane == 0 && g0 + g1 + g2 + g3 > 0) wbase = atomicAdd(&pd.level_counts[t + 1], g0 + g1 + g2 + g3);
     wbase = __shfl(wbase, 0, 64);
     const int gidx = lane >> 4;
     int slot = wbase + (gidx > 0 ? g0 : 0) + (gidx > 1 ? g1 : 0) + (gidx > 2 ? g2 : 0);
@@ -274,9 +278,10 @@ __device__ __forceinline__ bool pivot_from_record(const double* __restrict__ P, 
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, PrefixDev pd,
-                                                              const double* roots, int nroots,
-                                                              unsigned long long begin,
+                                                              const double* roots, int root_level,
+                                                              int root_cap, unsigned long long begin,
                                                               unsigned long long end) {
+    const int nroots = min(pd.level_counts[root_level], root_cap);
     constexpr int S5 = NMX + 5, S4 = NMX + 4, S3 = NMX + 3;
     __shared__ __attribute__((aligned(16))) double s_pool[SWEEP_GROUPS * POOLC * PG];
     __shared__ MuDesc s_desc[SWEEP_GROUPS * MAXMU];
@@ -622,37 +627,42 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     int launches = 0;
     int cur = (D0 % 2 == 0) ? 0 : 1;  // buffer of level 0, so that level D0 is buffer 0
+    // All levels and the leaf kernel are queued without a host round trip: every level's record
+    // count stays on the device (level_counts[t]); grids are sized for the combinatorial upper
+    // bound C(n-m+t, t) of the level (blocks beyond the actual count return at once).
+    std::memset(p->h_level_counts, 0, sizeof(int) * 32);
+    p->h_level_counts[0] = 1;
+    LP_HIP(ctx, hipMemcpyAsync(pd.level_counts, p->h_level_counts, sizeof(int) * 32, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_enum_root, 1, 64, 0, s, d, p->prefix_buf[cur]);
     ++launches;
-    int count = 1;
+    int caps[32];
+    caps[0] = 1;
     for (int t = 0; t < D0; ++t) {
-        LP_HIP(ctx, hipMemsetAsync(pd.level_count, 0, sizeof(int), s));
         const int nxt = cur ^ 1;
         const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1) * sizeof(double));
         const int cap = cap64 > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)cap64;
+        caps[t + 1] = cap;
+        const uint64_t bound = std::min<uint64_t>(lp_host_binom(n - m + t, t), 0x7FFFFFFFULL);
         const int groups_per_block = 256 / PG;
-        hipLaunchKernelGGL(k_enum_expand, lp_ceil_div(count, groups_per_block), 256, 0, s, d, pd, t,
-                           p->prefix_buf[cur], count, p->prefix_buf[nxt], cap, (unsigned long long)begin,
-                           (unsigned long long)end);
+        hipLaunchKernelGGL(k_enum_expand, (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block), 256, 0, s, d,
+                           pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
+                           (unsigned long long)begin, (unsigned long long)end);
         ++launches;
-        LP_HIP(ctx, hipMemcpyAsync(p->h_level_count, pd.level_count, sizeof(int), hipMemcpyDeviceToHost, s));
-        LP_HIP(ctx, hipStreamSynchronize(s));
-        count = *p->h_level_count;
-        if (count > cap) count = cap;
         cur = nxt;
-        if (count == 0) break;
     }
-    if (count > 0 && use_leaf) {
-        lp_enum_launch_leaves(p, p->prefix_buf[cur], count, begin, end);
+    const uint64_t root_bound = std::min<uint64_t>(lp_host_binom(n - m + D0, D0), 0x7FFFFFFFULL);
+    if (use_leaf) {
+        lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0, begin, end);
         ++launches;
-    } else if (count > 0) {
+    } else {
         // two workgroups per CU are resident (<= 256 VGPRs, 52 KB LDS each); a few more than that so
         // that the tail is filled by the dynamic root dealing
-        const int grid = std::min(lp_ceil_div(count, SWEEP_GROUPS), ctx->num_cus * 4);
-        hipLaunchKernelGGL(k_enum_sweep, grid, SWEEP_THREADS, 0, s, d, pd,
-                           p->prefix_buf[cur], count, (unsigned long long)begin, (unsigned long long)end);
+        const int grid = (int)std::min<uint64_t>(lp_ceil_div<uint64_t>(root_bound, SWEEP_GROUPS), (uint64_t)ctx->num_cus * 4);
+        hipLaunchKernelGGL(k_enum_sweep, grid, SWEEP_THREADS, 0, s, d, pd, p->prefix_buf[cur], D0, caps[D0],
+                           (unsigned long long)begin, (unsigned long long)end);
         ++launches;
     }
+    LP_HIP(ctx, hipMemcpyAsync(p->h_level_counts, pd.level_counts, sizeof(int) * 32, hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -665,6 +675,8 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         fprintf(stderr, "[enum_prefix] rounds %llu  cycles/round: advance %.0f produce %.0f pairs %.0f  pairs/round %.1f\n",
                 h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3]);
     }
+    for (int t = 1; t <= D0; ++t)
+        if (p->h_level_counts[t] > caps[t]) return LP_ITER_LIMIT;  // a level buffer was too small
     if (*p->h_overflow != 0 || *p->h_list_count > pd.list_cap) return LP_ITER_LIMIT;  // fall back
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));

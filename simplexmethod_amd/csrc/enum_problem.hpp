@@ -51,7 +51,7 @@ constexpr int kPairTabStride = 192;  // >= C(19,2)
 
 // Shared-prefix path (enum_prefix.hip)
 struct PrefixDev {
-    int* level_count;                 // records written by the current expand launch
+    int* level_counts;                // [32]: records of each tree level (level 0 = 1), device side
     int* overflow;                    // != 0: a buffer was too small, the caller falls back
     int* root_cursor;                 // next depth-D0 record to be taken by a sweep group
     unsigned long long* list;         // ranks of feasible subsets
@@ -88,7 +88,7 @@ struct lp_enum_problem {
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
     unsigned* dcomb6 = nullptr;
-    int* h_level_count = nullptr;              // pinned
+    int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned
     int* h_overflow = nullptr;                 // pinned
     bool list_valid = false;                   // the feasible list of the last prefix pass 1 is usable
@@ -109,8 +109,8 @@ int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
 
 // enum_leaf.hip: one lane per subset below the depth m-6 records
-int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots, uint64_t begin,
-                          uint64_t end);
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots_bound, int root_level,
+                          uint64_t begin, uint64_t end);
 
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
