@@ -275,7 +275,9 @@ __global__ void k_crash_finish(SimplexDev d) {
 
 __global__ __launch_bounds__(256) void k_permute_rows(SimplexDev d, const double* src, double* dst) {
     const int t = blockIdx.x;  // destination row, 0..m
-    const int s = (t < d.m) ? d.rowpos[t] : d.m;
+    // rowpos[] is complete only if all m crash pivots succeeded; after a singular verdict the
+    // tableau is never used again and rows are copied in place (rowpos[t..] was never written)
+    const int s = (t < d.m && d.state->status == kRunning) ? d.rowpos[t] : t;
     const double2* a = reinterpret_cast<const double2*>(src + (size_t)s * d.ld);
     double2* b = reinterpret_cast<double2*>(dst + (size_t)t * d.ld);
     for (int j = threadIdx.x; j < (d.ld >> 1); j += blockDim.x) b[j] = a[j];

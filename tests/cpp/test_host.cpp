@@ -150,4 +150,4 @@ TEST(Parser_InputSymmetricFixture) {
     CHECK(c->GetConstraintsMatrix().cols() == 5 && c->GetBasisIndices()[0] == 3 && c->GetBasisIndices()[1] == 4);
 }
 
-int main() { return run_all(); }
+int main(int argc, char** argv) { return run_all(argc > 1 ? argv[1] : nullptr); }

@@ -84,4 +84,4 @@ TEST(Enumeration_MultiGpuShardsOnOneDevice) {
     CHECK(a.rank == b.rank && a.objective == b.objective);
 }
 
-int main() { return run_all(); }
+int main(int argc, char** argv) { return run_all(argc > 1 ? argv[1] : nullptr); }
