@@ -159,19 +159,22 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                 for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * TS + U[r]];
                 H[r] = tab[R * TS + U[r]];
             }
+            // Invariant: before step t, rows t..5 of E are the rows not yet used, in ascending
+            // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
+            // are the pivot rows of steps 0..t-1.  The chosen row p is ROTATED into position t
+            // (rows t..p-1 move down by one): afterwards every access below has a static index —
+            // no per-element "is this the pivot row" selects, and the 2x2 block is rows 4 and 5.
             double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
             double minp = minp0, maxp = maxp0;
             bool sing = false;
-            unsigned used6 = 0u;
 #pragma unroll
             for (int t = 0; t < KD - 2; ++t) {
-                // first unused row (ascending row order) of largest |entry|
                 double big = -1.0, piv = 0.0;
-                int p = 0;
+                int p = t;
 #pragma unroll
-                for (int r = 0; r < KD; ++r) {
+                for (int r = t; r < KD; ++r) {
                     const double a = fabs(E[r][t]);
-                    const bool take = !((used6 >> r) & 1u) && (a > big);
+                    const bool take = a > big;   // strict: ties keep the first (lowest) row
                     big = take ? a : big;
                     piv = take ? E[r][t] : piv;
                     p = take ? r : p;
@@ -181,35 +184,41 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                 maxp = fmax(maxp, big);
                 const double inv = 1.0 / piv;
                 INV[t] = inv;
+                // rotate row p to position t (columns t..5 and the rhs)
 #pragma unroll
-                for (int cc = t + 1; cc < KD; ++cc)
-                    PR[t][cc] = sel6(p, E[0][cc], E[1][cc], E[2][cc], E[3][cc], E[4][cc], E[5][cc]);
-                PRH[t] = sel6(p, H[0], H[1], H[2], H[3], H[4], H[5]);
+                for (int cc = t; cc <= KD; ++cc) {
+                    double pr = (cc < KD) ? E[t][cc < KD ? cc : 0] : H[t];
+#pragma unroll
+                    for (int r = t + 1; r < KD; ++r) {
+                        const double v = (cc < KD) ? E[r][cc < KD ? cc : 0] : H[r];
+                        pr = (r == p) ? v : pr;
+                    }
+#pragma unroll
+                    for (int r = KD - 1; r > t; --r) {
+                        if (cc < KD)
+                            E[r][cc < KD ? cc : 0] = (r <= p) ? E[r - 1][cc < KD ? cc : 0] : E[r][cc < KD ? cc : 0];
+                        else
+                            H[r] = (r <= p) ? H[r - 1] : H[r];
+                    }
+                    if (cc < KD) E[t][cc < KD ? cc : 0] = pr; else H[t] = pr;
+                }
+#pragma unroll
+                for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
+                PRH[t] = H[t];
 #pragma unroll
                 for (int r = 0; r < KD; ++r) {
-                    const bool isp = (r == p);
-                    const double lx = isp ? inv : -(E[r][t] * inv);
+                    if (r == t) continue;
+                    const double lx = -(E[r][t] * inv);
 #pragma unroll
-                    for (int cc = t + 1; cc < KD; ++cc)
-                        E[r][cc] = fma(lx, PR[t][cc], isp ? -0.0 : E[r][cc]);
-                    H[r] = fma(lx, PRH[t], isp ? -0.0 : H[r]);
+                    for (int cc = t + 1; cc < KD; ++cc) E[r][cc] = fma(lx, PR[t][cc], E[r][cc]);
+                    H[r] = fma(lx, PRH[t], H[r]);
                 }
-                used6 |= 1u << p;
+#pragma unroll
+                for (int cc = t + 1; cc < KD; ++cc) E[t][cc] = PR[t][cc] * inv;
+                H[t] = PRH[t] * inv;
             }
-            // ---- 2x2 block on the two rows still unused (ascending) and columns c[4], c[5]
-            int r1 = 0, r2 = 0;
-            {
-                unsigned fr = ~used6 & 0x3Fu;
-                r1 = fr ? __builtin_ctz(fr) : 0;
-                fr &= fr - 1u;
-                r2 = fr ? __builtin_ctz(fr) : r1;
-            }
-            const double a1 = sel6(r1, E[0][4], E[1][4], E[2][4], E[3][4], E[4][4], E[5][4]);
-            const double a2 = sel6(r2, E[0][4], E[1][4], E[2][4], E[3][4], E[4][4], E[5][4]);
-            const double b1 = sel6(r1, E[0][5], E[1][5], E[2][5], E[3][5], E[4][5], E[5][5]);
-            const double b2 = sel6(r2, E[0][5], E[1][5], E[2][5], E[3][5], E[4][5], E[5][5]);
-            const double h1 = sel6(r1, H[0], H[1], H[2], H[3], H[4], H[5]);
-            const double h2 = sel6(r2, H[0], H[1], H[2], H[3], H[4], H[5]);
+            // ---- 2x2 block on the two rows still unused (rows 4 < 5) and columns c[4], c[5]
+            const double a1 = E[4][4], a2 = E[5][4], b1 = E[4][5], b2 = E[5][5], h1 = H[4], h2 = H[5];
             const bool second = fabs(a2) > fabs(a1);
             const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
             const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
@@ -229,9 +238,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
             bool feas = (xa >= -1e-9) && (xb >= -1e-9);
             // the four rows pivoted in phase 1: back-substitution
 #pragma unroll
-            for (int r = 0; r < KD; ++r) {
+            for (int r = 0; r < KD - 2; ++r) {
                 const double x = fma(-E[r][5], xb, fma(-E[r][4], xa, H[r]));
-                if ((used6 >> r) & 1u) feas = feas && (x >= -1e-9);
+                feas = feas && (x >= -1e-9);
             }
             // ---- phase 2: rows already used by the prefix, one at a time
             // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
