@@ -249,8 +249,11 @@ def main():
     def first_fn(lo, hi, zstar, tol):
         return ep.first_within(lo, hi, zstar, tol)
 
+    # cost-balanced cut of the rank space (identical answer for any cut; see dist.py)
+    my_bounds = lpdist.balanced_shard_bounds(n, m, rank, world)
+
     def step():
-        return lpdist.enum_solve_sharded(comm, total, True, range_fn, first_fn)
+        return lpdist.enum_solve_sharded(comm, total, True, range_fn, first_fn, bounds=my_bounds)
 
     for _ in range(args.warmup):
         res = step()
@@ -271,7 +274,7 @@ def main():
     value = total * args.steps / elapsed
     flops_per_subset = (2.0 / 3.0) * m ** 3 + 2.0 * m ** 2
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    shard = (lpdist.shard_bounds(total, rank, world)[1] - lpdist.shard_bounds(total, rank, world)[0])
+    shard = my_bounds[1] - my_bounds[0]
 
     winner = ep.vertex(res["rank"], n - m) if res["feasible"] else None
     line = None
@@ -286,8 +289,8 @@ def main():
                 "workload": f"vertex enumeration C({n},{m})={total} subsets, dense random LP "
                             f"seed 0 (BASELINE configs[3]); rank space sharded over {world} GPU(s)",
                 "enum_algo": args.enum_algo, "subsets_per_gpu": shard,
-                "parallelism": f"rank-range shards x{world}, all-reduce(max)+all-reduce(min) "
-                               "of the incumbent",
+                "parallelism": f"cost-balanced rank-range shards x{world}, all-reduce(max)+"
+                               "all-reduce(min) of the incumbent",
             },
             "enum": {
                 "optimum": None if winner is None else winner["obj"],

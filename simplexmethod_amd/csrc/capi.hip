@@ -394,6 +394,8 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
     (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
+    (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.item_count);
+    if (p->h_item_count) (void)hipHostFree(p->h_item_count);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
     if (p->h_level_counts) (void)hipHostFree(p->h_level_counts);
     if (p->h_list_count) (void)hipHostFree(p->h_list_count);
@@ -464,6 +466,8 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
                 for (int qb = qa + 1; qb < R; ++qb) pairtab[(size_t)R * kPairTabStride + r++] = (unsigned short)(qa | (qb << 8));
         }
         LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
+        LP_TRY(hipMalloc(&pd.item_count, sizeof(int)));
+        LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
         LP_TRY(hipMalloc(&pd.root_cursor, sizeof(int)));
         LP_TRY(hipMalloc(&pd.list, sizeof(unsigned long long) * pd.list_cap));

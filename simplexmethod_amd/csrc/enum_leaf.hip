@@ -41,9 +41,50 @@ __device__ __forceinline__ double sel6(int r, double a0, double a1, double a2, d
     return v;
 }
 
+constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
+
+// Work items of the leaf kernel: one per (record, chunk of kChunk subsets), so that no item is
+// longer than 16 wave passes — a depth m-6 record can hold up to C(22,6) = 74,613 subsets, and a
+// rank-range shard of an 8-GPU run is only a few milliseconds of work in total.  One lane per
+// record; slots in the item table are allocated with one atomic per wave.
+__global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd,
+                                                         const double* __restrict__ roots,
+                                                         int root_level, int root_cap) {
+    const int n = d.n, D = d.m - KD;
+    const int nroots = min(pd.level_counts[root_level], root_cap);
+    const int rec = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int nch = 0;
+    if (rec < nroots) {
+        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(roots + (size_t)rec * rec_doubles(n, D) +
+                                                               (size_t)PG * (n - D + 1));
+        const int last = pm->last_col;
+        if (last != kHole) {
+            const int R = n - 1 - last;
+            if (R >= KD) {
+                const unsigned long long L = binom(d, R, KD);
+                nch = (int)((L + kChunk - 1) / kChunk);
+            }
+        }
+    }
+    // inclusive wave scan of nch
+    int incl = nch;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(pd.item_count, total);
+    base = __shfl(base, 63, 64);
+    int at = base + incl - nch;
+    for (int k = 0; k < nch; ++k, ++at)
+        if (at < pd.item_cap) pd.items[at] = make_int2(rec, k);
+}
+
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixDev pd,
                                                               const double* __restrict__ roots,
-                                                              int root_level, int root_cap, int chunks,
                                                               unsigned long long begin,
                                                               unsigned long long end) {
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
@@ -52,8 +93,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
     const int m = d.m, n = d.n, D = m - KD;
-    // device-side count of the depth-D records (clamped to what the buffer can hold)
-    const int nroots = min(pd.level_counts[root_level], root_cap);
+    const int nitems = min(*pd.item_count, pd.item_cap);   // built by k_enum_make_items
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
@@ -70,7 +110,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     // round trip of a record sits between two items.
     constexpr int NLOAD = (MAXCOLS * PG + 63) / 64;   // doubles per lane to hold one record
     const int rec_cols = n - D + 1;                   // columns of a record incl. rhs
-    const long long nitems = (long long)nroots * chunks;
     // items are drawn kDraw at a time: one returning atomic on a single word costs ~11 ns chip-wide,
     // which at one draw per record (5.3 M records for C(32,16)) would bound the whole kernel
     constexpr int kDraw = 16;
@@ -86,9 +125,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     };
     double pre[NLOAD];
     NodeMeta pmB;
+    int chunkB = 0;
     auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
-        const int node = item / chunks;
-        const double* Q = roots + (size_t)node * rec_doubles(n, D);
+        const int2 it = pd.items[item];
+        chunkB = it.y;
+        const double* Q = roots + (size_t)it.x * rec_doubles(n, D);
 #pragma unroll
         for (int q = 0; q < NLOAD; ++q) {
             const int k = lane + 64 * q;
@@ -103,7 +144,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     for (;;) {
         if (itemB >= nitems) break;
         // ---- item B becomes the current item: registers -> LDS slice (odd column stride)
-        const int item = itemB;
+        const int chunk = chunkB;
         const NodeMeta pm = pmB;
         double* tab = s_tab[wave * 2 + buf];
 #pragma unroll
@@ -115,7 +156,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
         itemB = itemC;
         itemC = draw();
         if (itemB < nitems) fetch(itemB);
-        const int chunk = item % chunks;
         if (pm.last_col == kHole) continue;
         const int R = n - 1 - pm.last_col;           // selectable columns
         if (R < KD) continue;
@@ -137,9 +177,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
         const double minp0 = pm.minp, maxp0 = pm.maxp;
         const unsigned long long rb = pm.rank_base;
 
-        const unsigned int per = (L + chunks - 1) / chunks;
-        const unsigned int leaf_lo = chunk * per;
-        const unsigned int leaf_hi = (leaf_lo + per < L) ? leaf_lo + per : L;
+        const unsigned int leaf_lo = (unsigned int)chunk * kChunk;
+        const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
             if (rank < begin || rank >= end) continue;
@@ -288,17 +327,25 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
 }  // namespace
 
 // nroots_bound: combinatorial upper bound of the record count (the actual count is read on the
-// device from level_counts[root_level]); it only sizes the grid and the chunking.
+// device from level_counts[root_level]); total = subsets in the pass (sizes the item table).
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots_bound, int root_level,
                           uint64_t begin, uint64_t end) {
-    const int nroots = nroots_bound;
     lp_context* ctx = p->ctx;
-    // at least ~16 work items per wave slot of the chip
-    const long long want = (long long)ctx->num_cus * 8 * LEAF_WAVES * 16;
-    int chunks = (int)std::min<long long>(64, std::max<long long>(1, want / std::max(nroots, 1)));
-    const long long items = (long long)nroots * chunks;
-    const int grid = (int)std::min<long long>(lp_ceil_div<long long>(items, LEAF_WAVES), (long long)ctx->num_cus * 8);
-    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, p->prefix, roots, root_level,
-                       nroots_bound, chunks, (unsigned long long)begin, (unsigned long long)end);
+    PrefixDev& pd = p->prefix;
+    const uint64_t total = lp_host_binom(p->dev.n, p->dev.m);
+    const uint64_t want = (uint64_t)nroots_bound + total / kChunk + 1024;
+    if ((uint64_t)pd.item_cap < want) {
+        if (pd.items) (void)hipFree(pd.items);
+        pd.items = nullptr;
+        pd.item_cap = 0;
+        LP_HIP(ctx, hipMalloc(&pd.items, sizeof(int2) * want));
+        pd.item_cap = (int)std::min<uint64_t>(want, 0x7FFFFFFFULL);
+    }
+    LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_enum_make_items, lp_ceil_div(nroots_bound, 256), 256, 0, ctx->stream, p->dev, pd,
+                       roots, root_level, nroots_bound);
+    const int grid = ctx->num_cus * 8;
+    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots,
+                       (unsigned long long)begin, (unsigned long long)end);
     return LP_OPTIMAL;
 }

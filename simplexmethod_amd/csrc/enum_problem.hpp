@@ -59,6 +59,9 @@ struct PrefixDev {
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
     const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
+    int2* items;                      // leaf-kernel work items: (record slot, chunk of its subsets)
+    int* item_count;
+    int item_cap;
     const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
                                       // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]
     unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
@@ -88,6 +91,7 @@ struct lp_enum_problem {
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
     unsigned* dcomb6 = nullptr;
+    int* h_item_count = nullptr;               // pinned
     int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned
     int* h_overflow = nullptr;                 // pinned

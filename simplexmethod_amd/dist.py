@@ -21,6 +21,77 @@ def shard_bounds(total, rank, world):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def _binom(n, k):
+    from math import comb
+    return comb(n, k) if 0 <= k <= n else 0
+
+
+def _unrank(n, m, rank):
+    """k-th sorted m-subset of {0..n-1} in lexicographic order (same order as the kernels)."""
+    s, a = [], 0
+    for t in range(m):
+        j = a
+        while True:
+            cnt = _binom(n - 1 - j, m - 1 - t)
+            if rank < cnt:
+                break
+            rank -= cnt
+            j += 1
+        s.append(j)
+        a = j + 1
+    return s
+
+
+def _lexrank(universe, subset):
+    r, a, k = 0, 0, len(subset)
+    for t, v in enumerate(subset):
+        for j in range(a, v):
+            r += _binom(universe - 1 - j, k - 1 - t)
+        a = v + 1
+    return r
+
+
+RECORD_COST = 26  # one depth m-6 record costs about as much as 26 subsets (measured on MI355X)
+
+
+def balanced_shard_bounds(n, m, rank, world, record_cost=RECORD_COST):
+    """Cut [0, C(n,m)) into `world` contiguous ranges of equal estimated COST rather than equal
+    size.  The shared-prefix enumeration pays per subset and per depth m-6 tree node, and the
+    nodes are not spread evenly along the rank axis (late prefixes have few subsets each), so
+    equal-size shards differ by up to 2x in run time.  cost(x) = x + record_cost * (number of
+    depth m-6 prefixes before the x-th subset), exact combinatorics on the host.  The solver's
+    answer does not depend on where the cuts are (tie rule of SURVEY.md 8 row E1)."""
+    total = _binom(n, m)
+    d0 = m - 6
+    if world <= 1 or d0 < 1 or total < (1 << 20):
+        return shard_bounds(total, rank, world)
+    universe = n - m + d0
+
+    def cost(x):
+        if x >= total:
+            return total + record_cost * _binom(universe, d0)
+        return x + record_cost * _lexrank(universe, _unrank(n, m, x)[:d0])
+
+    full = cost(total)
+
+    def cut(k):
+        if k <= 0:
+            return 0
+        if k >= world:
+            return total
+        target = full * k // world
+        lo, hi = 0, total
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if cost(mid) < target:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    return cut(rank), cut(rank + 1)
+
+
 class LocalComm:
     """world == 1: reductions are identities."""
     rank, world = 0, 1
@@ -70,15 +141,17 @@ class TorchComm:
         self.dist.barrier()
 
 
-def enum_solve_sharded(comm, total, maximize, range_fn, first_fn):
+def enum_solve_sharded(comm, total, maximize, range_fn, first_fn, bounds=None):
     """Runs pass 1 / pass 2 on this process's shard and reduces over `comm`.
 
     range_fn(begin, end) -> (zbest (±inf if no feasible subset), counts[3])
     first_fn(begin, end, zstar, tol) -> smallest qualifying rank or U64_MAX
+    bounds: this process's (begin, end); default = equal-size cut (shard_bounds), or pass
+            balanced_shard_bounds(n, m, rank, world) for the cost-balanced cut
     Returns dict(feasible, zstar, rank, counts) — identical on every process and for every
     `world` (the tie rule does not depend on how the range was cut).
     """
-    lo, hi = shard_bounds(total, comm.rank, comm.world)
+    lo, hi = bounds if bounds is not None else shard_bounds(total, comm.rank, comm.world)
     z, counts = range_fn(lo, hi)
     score = z if maximize else -z
     if np.isnan(score):

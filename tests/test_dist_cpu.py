@@ -92,3 +92,24 @@ def test_local_comm_single_process():
         lambda lo, hi: o.enum_range(A, b, c, True, lo, hi)[1:],
         lambda lo, hi, z, tol: o.enum_first_within(A, b, c, True, lo, hi, z, tol))
     assert res == dict(feasible=True, zstar=35.0, rank=2, counts=[7, 3, 0])
+
+
+def test_balanced_shard_bounds_cover_and_match_oracle_ranking():
+    from oracle import pyoracle as o
+    from simplexmethod_amd import dist as lpdist
+    # the host-side combinatorics agree with the oracle's
+    for n, m, k in [(9, 4, 77), (20, 10, 123456), (32, 16, 592101131)]:
+        assert lpdist._unrank(n, m, k) == o.unrank(n, m, k).tolist()
+    for n, m in [(32, 16), (28, 14), (24, 8)]:
+        total = o.binom(n, m)
+        for world in (2, 3, 8):
+            cuts = [lpdist.balanced_shard_bounds(n, m, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+            assert all(hi > lo for lo, hi in cuts)
+    # early shards (few, large subtrees) are longer than late ones in subsets, never the reverse
+    cuts = [lpdist.balanced_shard_bounds(32, 16, r, 8) for r in range(8)]
+    sizes = [hi - lo for lo, hi in cuts]
+    assert sizes[0] > sizes[-1]
+    # small trees keep the equal-size cut
+    assert lpdist.balanced_shard_bounds(12, 5, 1, 2) == lpdist.shard_bounds(o.binom(12, 5), 1, 2)
