@@ -393,7 +393,7 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6); (void)hipFree(p->dcomb7);
     (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.item_count);
     if (p->h_item_count) (void)hipHostFree(p->h_item_count);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
@@ -469,7 +469,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipMalloc(&pd.item_count, sizeof(int)));
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
-        LP_TRY(hipMalloc(&pd.root_cursor, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
         LP_TRY(hipMalloc(&pd.list, sizeof(unsigned long long) * pd.list_cap));
         LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
         LP_TRY(hipMalloc(&pd.scores, sizeof(double) * pd.list_cap));
@@ -498,8 +498,26 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         }
         LP_TRY(hipMalloc(&p->dcomb6, sizeof(unsigned) * comb6.size()));
         LP_TRY(hipMemcpyAsync(p->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
-        LP_TRY(hipStreamSynchronize(s));  // comb6 is a local
+        // thin leaf kernel: 7-subsets of 7, 8 and 9 columns, 4 bits per index
+        std::vector<unsigned> comb7(3 * 36, 0u);
+        for (int R9 = 7; R9 <= 9; ++R9) {
+            int s7[7] = {0, 1, 2, 3, 4, 5, 6};
+            for (int k = 0;; ++k) {
+                unsigned pk = 0;
+                for (int t = 0; t < 7; ++t) pk |= (unsigned)s7[t] << (4 * t);
+                comb7[(size_t)36 * (R9 - 7) + k] = pk;
+                int t = 6;
+                while (t >= 0 && s7[t] == R9 - 7 + t) --t;
+                if (t < 0) break;
+                ++s7[t];
+                for (int u = t + 1; u < 7; ++u) s7[u] = s7[u - 1] + 1;
+            }
+        }
+        LP_TRY(hipMalloc(&p->dcomb7, sizeof(unsigned) * comb7.size()));
+        LP_TRY(hipMemcpyAsync(p->dcomb7, comb7.data(), sizeof(unsigned) * comb7.size(), hipMemcpyHostToDevice, s));
+        LP_TRY(hipStreamSynchronize(s));  // comb6 / comb7 are locals
         pd.comb6 = p->dcomb6;
+        pd.comb7 = p->dcomb7;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

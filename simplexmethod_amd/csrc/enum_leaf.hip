@@ -1,9 +1,11 @@
 // enum_leaf.hip — leaf kernel of the shared-prefix enumeration: ONE LANE PER SUBSET.
 //
-// Input: the depth D = m-6 records produced breadth-first by k_enum_expand (enum_prefix.hip):
-// the tableau [W[:, c > last] | rhs] after the first m-6 Gauss-Jordan steps, shared by every
-// subset with that prefix.  A wave owns one record at a time, copies its live columns to its
-// private LDS slice, and each of its 64 lanes then finishes one subset on its own: it picks
+// Input: the depth m-7 records produced breadth-first by k_enum_expand (enum_prefix.hip): the
+// tableau [W[:, c > last] | rhs] after the first m-7 Gauss-Jordan steps, shared by every subset
+// with that prefix.  A wave owns one work item (record, child column, chunk of subsets) at a
+// time: it copies the record to its private LDS slice, performs the pivot on the child column
+// cooperatively (16 rows x 4 columns per step; the depth m-6 tableau never travels through
+// HBM), and each of its 64 lanes then finishes one subset on its own: it picks
 // the remaining KD = 6 columns (lexicographic unranking of its leaf index), replays the last
 // four Gauss-Jordan steps and the 2x2 block exactly as oracle/lp_oracle.c: orc_enum_subset
 // orders them, and tests feasibility.  No cross-lane traffic, no barriers, no divergence
@@ -23,50 +25,64 @@ using namespace lptree;
 
 namespace {
 
-constexpr int KD = 6;                 // columns chosen per lane
 constexpr int LEAF_THREADS = 256;
 constexpr int LEAF_WAVES = LEAF_THREADS / 64;
-constexpr int MAXCOLS = NMX + KD + 1;  // live columns of a depth m-6 record (+ rhs)
+constexpr int THIN_TAIL = 9;          // the thin kernel takes the subsets inside the last 9 columns
 constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
                                       // same row of different columns hit different banks
 
-__device__ __forceinline__ double sel6(int r, double a0, double a1, double a2, double a3, double a4,
-                                       double a5) {
-    double v = a0;
-    v = (r == 1) ? a1 : v;
-    v = (r == 2) ? a2 : v;
-    v = (r == 3) ? a3 : v;
-    v = (r == 4) ? a4 : v;
-    v = (r == 5) ? a5 : v;
-    return v;
-}
-
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
 
-// Work items of the leaf kernel: one per (record, chunk of kChunk subsets), so that no item is
-// longer than 16 wave passes — a depth m-6 record can hold up to C(22,6) = 74,613 subsets, and a
-// rank-range shard of an 8-GPU run is only a few milliseconds of work in total.  One lane per
-// record; slots in the item table are allocated with one atomic per wave.
+// Work items of the leaf kernel: (record, child column, chunk of kChunk subsets, rank offset of the
+// child inside the record), so that no item is longer than 16 wave passes — a depth m-6 node can
+// hold up to C(22,6) = 74,613 subsets, and a rank-range shard of an 8-GPU run is only a few
+// milliseconds of work in total.  One lane per record; slots in the item table are allocated with
+// one atomic per wave.  FUSED: records are depth m-7 nodes and an item names one of their children
+// (those with at least min_child_R selectable columns; the thin kernel takes the rest);
+// otherwise (m = 6) the one record is the depth m-6 root itself.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd,
                                                          const double* __restrict__ roots,
-                                                         int root_level, int root_cap) {
-    const int n = d.n, D = d.m - KD;
+                                                         int root_level, int root_cap, int min_child_R,
+                                                         unsigned long long begin,
+                                                         unsigned long long end) {
+    constexpr int KD = 6;
+    const int n = d.n, m = d.m, D = m - KD - (FUSED ? 1 : 0);
     const int nroots = min(pd.level_counts[root_level], root_cap);
     const int rec = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int nch = 0;
+    int nch = 0, last = kHole;
+    unsigned long long rb0 = 0ULL;
     if (rec < nroots) {
         const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(roots + (size_t)rec * rec_doubles(n, D) +
                                                                (size_t)PG * (n - D + 1));
-        const int last = pm->last_col;
-        if (last != kHole) {
-            const int R = n - 1 - last;
-            if (R >= KD) {
-                const unsigned long long L = binom(d, R, KD);
-                nch = (int)((L + kChunk - 1) / kChunk);
-            }
-        }
+        last = pm->last_col;
+        rb0 = pm->rank_base;
     }
+    // children a (FUSED) or the node itself: chunks whose rank interval meets [begin, end)
+    auto visit = [&](auto&& emit) {
+        if (last == kHole) return;
+        if (FUSED) {
+            unsigned long long rb = rb0;
+            const int lim = n - m + D;  // largest column selectable at depth D
+            for (int a = last + 1; a <= lim; ++a) {
+                const int R = n - 1 - a;
+                const unsigned long long L = binom(d, R, KD);
+                if (R >= min_child_R)
+                    for (unsigned long long lo = 0; lo < L; lo += kChunk)
+                        if (overlap(rb + lo, (L - lo < kChunk) ? L - lo : (unsigned long long)kChunk, begin, end))
+                            emit(a, (int)(lo / kChunk), (int)(rb - rb0));
+                rb += L;
+            }
+        } else {
+            const int R = n - 1 - last;
+            const unsigned long long L = binom(d, R, KD);
+            for (unsigned long long lo = 0; lo < L; lo += kChunk)
+                if (overlap(rb0 + lo, (L - lo < kChunk) ? L - lo : (unsigned long long)kChunk, begin, end))
+                    emit(last, (int)(lo / kChunk), 0);
+        }
+    };
+    visit([&](int, int, int) { ++nch; });
     // inclusive wave scan of nch
     int incl = nch;
 #pragma unroll
@@ -79,28 +95,48 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
     if (lane == 63 && total > 0) base = atomicAdd(pd.item_count, total);
     base = __shfl(base, 63, 64);
     int at = base + incl - nch;
-    for (int k = 0; k < nch; ++k, ++at)
-        if (at < pd.item_cap) pd.items[at] = make_int2(rec, k);
+    visit([&](int a, int chunk, int roff) {
+        if (at < pd.item_cap) pd.items[at] = make_int4(rec, a, chunk, roff);
+        ++at;
+    });
 }
 
-__global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixDev pd,
+// KD = columns chosen per lane.
+//   <6, false, true>   the regular kernel: work items (record, child, chunk) over the depth m-7
+//                      records; the wave pivots on the child column itself (FUSED), the lanes take
+//                      the 6 remaining columns.
+//   <7, true, false>   "thin": over the same depth m-7 records, it takes exactly the subsets that
+//                      lie inside the last THIN_TAIL = 9 selectable columns — the ones whose depth
+//                      m-6 node would hold fewer than 29 subsets.  Those nodes are 78 % of their
+//                      level but carry 6 % of the subsets; each would cost a pivot and a nearly
+//                      empty wave pass.
+//   <6, false, false>  m = 6: the root record is the depth m-6 node.
+template <int KD, bool THIN, bool FUSED>
+__global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(KD == 6 ? 3 : 2)))
+void k_enum_leaves(EnumDev d, PrefixDev pd,
                                                               const double* __restrict__ roots,
+                                                              int root_level, int root_cap,
                                                               unsigned long long begin,
                                                               unsigned long long end) {
+    constexpr int MAXCOLS = NMX + KD + 1 + (FUSED ? 1 : 0);  // columns of a record (+ rhs)
+    constexpr int CHILDCOLS = NMX + KD + 1;                  // columns of a depth m-KD tableau (+ rhs)
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
-    __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= 23, k <= 6
+    __shared__ __attribute__((aligned(16))) double s_child[FUSED ? LEAF_WAVES : 1][FUSED ? CHILDCOLS * TS : 1];
+    __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
     __shared__ unsigned long long s_cnt[3];
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
-    const int m = d.m, n = d.n, D = m - KD;
-    const int nitems = min(*pd.item_count, pd.item_cap);   // built by k_enum_make_items
+    const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
+    const int nitems = THIN ? min(pd.level_counts[root_level], root_cap)
+                            : min(*pd.item_count, pd.item_cap);   // built by k_enum_make_items
+    int* const cursor = pd.root_cursor + (THIN ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
-    if (tid < 32) s_off[tid] = pd.comb6[tid];
+    if (tid < 32) s_off[tid] = THIN ? 0u : pd.comb6[tid];
     __syncthreads();
     unsigned int cntF = 0, cntI = 0, cntS = 0;
 
@@ -110,26 +146,43 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     // round trip of a record sits between two items.
     constexpr int NLOAD = (MAXCOLS * PG + 63) / 64;   // doubles per lane to hold one record
     const int rec_cols = n - D + 1;                   // columns of a record incl. rhs
-    // items are drawn kDraw at a time: one returning atomic on a single word costs ~11 ns chip-wide,
-    // which at one draw per record (5.3 M records for C(32,16)) would bound the whole kernel
-    constexpr int kDraw = 16;
-    int draw_next = 0, draw_end = 0;
+    // Items are dealt in runs: one returning atomic on a single word costs ~11 ns chip-wide, which
+    // at one draw per item would bound the whole kernel (2 M records for C(32,16) in the thin one).
+    // The first deal is static — wave w owns items [w*k0, (w+1)*k0) — so that the launch does not
+    // open with two atomics per wave on that word (~0.2 ms for a full grid); later runs shrink with
+    // what is left (guided self-scheduling: a wave holding a long run while the others have
+    // finished is the kernel's tail), and a wave whose last run reached the end of the table does
+    // not ask again.
+    constexpr int kMaxRun = THIN ? 16 : 4;
+    const int nwaves = (int)gridDim.x * LEAF_WAVES;
+    const int k0 = max(1, min(kMaxRun, nitems / (nwaves * 4)));
+    const int dyn_base = nwaves * k0;
+    int draw_next = ((int)blockIdx.x * LEAF_WAVES + wave) * k0, draw_end = draw_next + k0;
+    int seen = dyn_base;   // lower bound of the cursor position
     auto draw = [&]() {
-        if (draw_next == draw_end) {
+        if (draw_next == draw_end && draw_end < nitems) {
+            const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
             int v = 0;
-            if (lane == 0) v = atomicAdd(pd.root_cursor, kDraw);
-            draw_next = __builtin_amdgcn_readfirstlane(v);
-            draw_end = draw_next + kDraw;
+            if (lane == 0) v = atomicAdd(cursor, k);
+            draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            draw_end = draw_next + k;
+            seen = draw_end;
         }
         return draw_next++;
     };
     double pre[NLOAD];
     NodeMeta pmB;
-    int chunkB = 0;
+    int chunkB = 0, childB = 0, roffB = 0;
     auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
-        const int2 it = pd.items[item];
-        chunkB = it.y;
-        const double* Q = roots + (size_t)it.x * rec_doubles(n, D);
+        int rec = item;
+        if (!THIN) {
+            const int4 it = pd.items[item];
+            rec = it.x;
+            childB = it.y;
+            chunkB = it.z;
+            roffB = it.w;
+        }
+        const double* Q = roots + (size_t)rec * rec_doubles(n, D);
 #pragma unroll
         for (int q = 0; q < NLOAD; ++q) {
             const int k = lane + 64 * q;
@@ -144,7 +197,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
     for (;;) {
         if (itemB >= nitems) break;
         // ---- item B becomes the current item: registers -> LDS slice (odd column stride)
-        const int chunk = chunkB;
+        const int chunk = chunkB, child = childB, roff = roffB;
         const NodeMeta pm = pmB;
         double* tab = s_tab[wave * 2 + buf];
 #pragma unroll
@@ -157,14 +210,54 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
         itemC = draw();
         if (itemB < nitems) fetch(itemB);
         if (pm.last_col == kHole) continue;
-        const int R = n - 1 - pm.last_col;           // selectable columns
+        const int last = FUSED ? child : pm.last_col;  // last chosen column of the depth m-KD node
+        const int R = n - 1 - last;                    // selectable columns
         if (R < KD) continue;
-        const int first = pm.last_col + 1 - D;       // slice column of the first live column
-        tab += first * TS;                           // column q below = column last+1+q
-        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, 6) leaves below this node
-        const unsigned* comb = pd.comb6 + s_off[R];
-        // rows: the 6 not used by the prefix (ascending), and the used ones
-        const unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
+        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, KD) subsets below this node
+        // subset table: all KD-subsets in lexicographic order, packed (5 or 4 bits per index)
+        const int R9 = R < THIN_TAIL ? R : THIN_TAIL;
+        const unsigned* comb = THIN ? pd.comb7 + 36 * (R9 - 7) : pd.comb6 + s_off[R];
+        const unsigned int tail = THIN ? s_binom[R9 * (KD + 1) + KD] : 0u;  // C(min(R,9), 7)
+        const unsigned long long rb = pm.rank_base + (unsigned long long)(FUSED ? roff : 0);
+        // thin: the last `tail` subsets of the node (those inside its last 9 columns)
+        const unsigned int leaf_lo = THIN ? L - tail : (unsigned int)chunk * kChunk;
+        const unsigned int leaf_hi = THIN ? L : ((leaf_lo + kChunk < L) ? leaf_lo + kChunk : L);
+        double minp0 = pm.minp, maxp0 = pm.maxp;
+        unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
+        if (FUSED) {
+            // ---- the wave pivots on column `child`: lane = (row r, column group g), exactly the
+            // arithmetic of k_enum_expand (first unused row of largest |w|; l = -(w/piv) as w * (1/piv))
+            const int r = lane & (PG - 1), g = lane >> 4;
+            const bool row_used = (r >= m) || ((umask >> r) & 1u);
+            const double* pcol = tab + (child - D) * TS;
+            const double w = pcol[r];
+            double big;
+            const int p = __builtin_amdgcn_readfirstlane(pick_pivot_row(w, row_used, lane & ~(PG - 1), big));
+            minp0 = fmin(minp0, big);
+            maxp0 = fmax(maxp0, big);
+            if (!(big > 0.0) || minp0 <= DBL_EPSILON * (double)m * maxp0) {
+                // every subset below this node is singular
+                if (lane == 0) cntS += (unsigned int)overlap(rb + leaf_lo, leaf_hi - leaf_lo, begin, end);
+                continue;
+            }
+            const double inv = 1.0 / pcol[p];
+            const bool isp = (r == p);
+            const double lx = isp ? inv : -(w * inv);
+            double* ctab = s_child[wave];
+#pragma unroll
+            for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
+                const int j = g + 4 * q;            // child column j = column child+1+j (j = R: rhs)
+                if (j <= R) {
+                    const double* pc = tab + (child + 1 + j - D) * TS;
+                    ctab[j * TS + r] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
+                }
+            }
+            umask |= 1u << p;
+            tab = ctab;
+        } else {
+            tab += (last + 1 - D) * TS;              // column q below = column last+1+q
+        }
+        // rows: the KD not used by the prefix (ascending), and the used ones
         int U[KD];
         {
             unsigned free_rows = ~umask & ((1u << m) - 1u);
@@ -174,18 +267,18 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                 free_rows &= free_rows - 1u;
             }
         }
-        const double minp0 = pm.minp, maxp0 = pm.maxp;
-        const unsigned long long rb = pm.rank_base;
 
-        const unsigned int leaf_lo = (unsigned int)chunk * kChunk;
-        const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
             if (rank < begin || rank >= end) continue;
             // ---- the leaf's 6 columns: table of all 6-subsets of R columns in lexicographic order
             // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
             int c[KD];
-            {
+            if (THIN) {
+                const unsigned pk = comb[leaf - leaf_lo];
+#pragma unroll
+                for (int t = 0; t < KD; ++t) c[t] = (R - R9) + (int)((pk >> (4 * t)) & 15u);
+            } else {
                 const unsigned pk = comb[leaf];
 #pragma unroll
                 for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
@@ -257,7 +350,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                 H[t] = PRH[t] * inv;
             }
             // ---- 2x2 block on the two rows still unused (rows 4 < 5) and columns c[4], c[5]
-            const double a1 = E[4][4], a2 = E[5][4], b1 = E[4][5], b2 = E[5][5], h1 = H[4], h2 = H[5];
+            const double a1 = E[KD - 2][KD - 2], a2 = E[KD - 1][KD - 2], b1 = E[KD - 2][KD - 1],
+                         b2 = E[KD - 1][KD - 1], h1 = H[KD - 2], h2 = H[KD - 1];
             const bool second = fabs(a2) > fabs(a1);
             const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
             const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
@@ -278,7 +372,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
             // the four rows pivoted in phase 1: back-substitution
 #pragma unroll
             for (int r = 0; r < KD - 2; ++r) {
-                const double x = fma(-E[r][5], xb, fma(-E[r][4], xa, H[r]));
+                const double x = fma(-E[r][KD - 1], xb, fma(-E[r][KD - 2], xa, H[r]));
                 feas = feas && (x >= -1e-9);
             }
             // ---- phase 2: rows already used by the prefix, one at a time
@@ -301,7 +395,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
                         for (int cc = t + 1; cc < KD; ++cc) v[cc] = fma(lx, PR[t][cc], v[cc]);
                         h = fma(lx, PRH[t], h);
                     }
-                    const double x = fma(-v[5], xb, fma(-v[4], xa, h));
+                    const double x = fma(-v[KD - 1], xb, fma(-v[KD - 2], xa, h));
                     feas = feas && (x >= -1e-9);
                     alive = alive && feas;
                 }
@@ -326,26 +420,39 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_leaves(EnumDev d, PrefixD
 
 }  // namespace
 
-// nroots_bound: combinatorial upper bound of the record count (the actual count is read on the
-// device from level_counts[root_level]); total = subsets in the pass (sizes the item table).
-int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots_bound, int root_level,
-                          uint64_t begin, uint64_t end) {
+// Second phase of the shared-prefix pass over the records of the last breadth-first level
+// (`roots`, count in level_counts[level], at most `bound`): depth m-7 records (fused = true: the
+// regular kernel pivots once more itself, the thin kernel takes the small tails) or, for m = 6, the
+// root record.  `bound6` bounds the number of depth m-6 nodes (sizes the item table).
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
+                          uint64_t bound6, uint64_t begin, uint64_t end) {
     lp_context* ctx = p->ctx;
     PrefixDev& pd = p->prefix;
     const uint64_t total = lp_host_binom(p->dev.n, p->dev.m);
-    const uint64_t want = (uint64_t)nroots_bound + total / kChunk + 1024;
+    const uint64_t want = bound6 + total / kChunk + 1024;
     if ((uint64_t)pd.item_cap < want) {
         if (pd.items) (void)hipFree(pd.items);
         pd.items = nullptr;
         pd.item_cap = 0;
-        LP_HIP(ctx, hipMalloc(&pd.items, sizeof(int2) * want));
+        LP_HIP(ctx, hipMalloc(&pd.items, sizeof(int4) * want));
         pd.item_cap = (int)std::min<uint64_t>(want, 0x7FFFFFFFULL);
     }
     LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_enum_make_items, lp_ceil_div(nroots_bound, 256), 256, 0, ctx->stream, p->dev, pd,
-                       roots, root_level, nroots_bound);
-    const int grid = ctx->num_cus * 8;
-    hipLaunchKernelGGL(k_enum_leaves, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots,
-                       (unsigned long long)begin, (unsigned long long)end);
+    // persistent waves (items are dealt dynamically): as many blocks as are resident
+    const int grid6 = ctx->num_cus * 3, grid7 = ctx->num_cus * 2;
+    const unsigned long long b = begin, e = end;
+    if (fused) {
+        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, THIN_TAIL, b, e);
+        hipLaunchKernelGGL((k_enum_leaves<6, false, true>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, b, e);
+        hipLaunchKernelGGL((k_enum_leaves<7, true, false>), grid7, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, b, e);
+    } else {
+        hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, 0, b, e);
+        hipLaunchKernelGGL((k_enum_leaves<6, false, false>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, b, e);
+    }
     return LP_OPTIMAL;
 }

@@ -131,6 +131,80 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
 }
 
+// The same expansion for NARROW levels (the first few, and every level of a small rank range):
+// one WAVE per (parent, child) — lane = (row, column quarter) — with all of the child's columns
+// in flight at once.  A lone 16-lane group pivoting up to n-m+1 children one after the other, four
+// dependent HBM round trips per child, takes ~60 us per level: most of a small shard's run time.
+__global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev pd, int t,
+                                                            const double* __restrict__ src, int src_cap,
+                                                            double* __restrict__ dst, int dst_cap,
+                                                            unsigned long long begin,
+                                                            unsigned long long end) {
+    const int m = d.m, n = d.n, S = n - m + 1;   // S = most children a node can have
+    const int lane = threadIdx.x & 63, gl = lane & (PG - 1), g = lane >> 4, gbase = lane & ~(PG - 1);
+    const int wid = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int node = wid / S, j = wid - node * S;
+    const int nsrc = min(pd.level_counts[t], src_cap);
+    if (node >= nsrc) return;
+    const double* P = src + (size_t)node * rec_doubles(n, t);
+    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
+    const int a = pm.last_col + 1 + j;
+    if (pm.last_col == kHole || a > n - m + t) return;
+    unsigned long long rb = pm.rank_base;
+    for (int a2 = pm.last_col + 1; a2 < a; ++a2) rb += binom(d, n - 1 - a2, m - t - 1);
+    const unsigned long long ov = overlap(rb, binom(d, n - 1 - a, m - t - 1), begin, end);
+    if (ov == 0ULL) return;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&pd.level_counts[t + 1], 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= dst_cap) {
+        if (lane == 0) atomicExch(pd.overflow, 1);
+        return;
+    }
+    double* C = dst + (size_t)slot * rec_doubles(n, t + 1);
+    NodeMeta* cmeta = reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t));
+    const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
+    const double w = P[(size_t)(a - t) * PG + gl];
+    // this group's columns (a+1+g, a+5+g, ...; column n = the rhs): all loads issued before use
+    constexpr int NC = (PG + NMX + 1 + 3) / 4;   // n <= 32 on this path: at most 33 columns
+    double own[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = a + 1 + g + 4 * q;
+        own[q] = (c <= n) ? P[(size_t)(c - t) * PG + gl] : 0.0;
+    }
+    double big;
+    const int p = pick_pivot_row(w, prow_used, gbase, big);
+    const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
+    if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
+        if (lane == 0) {
+            cmeta->last_col = kHole;  // the whole subtree is singular
+            atomicAdd(&d.result->counts[2], ov);
+        }
+        return;
+    }
+    const int addr = (gbase + p) << 2;
+    const double inv = 1.0 / bcast16(w, addr);
+    const bool isp = (gl == p);
+    const double lx = isp ? inv : -(w * inv);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = a + 1 + g + 4 * q;
+        const double pc = bcast16(own[q], addr);
+        if (c <= n) C[(size_t)(c - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own[q]);
+    }
+    if (lane == 0) {
+        NodeMeta cm;
+        cm.rank_base = rb;
+        cm.minp = minp;
+        cm.maxp = maxp;
+        cm.last_col = a;
+        cm.used_mask = pm.used_mask | (1u << p);
+        for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+        *cmeta = cm;
+    }
+}
+
 // root record (depth 0): the original [A | b]
 __global__ void k_enum_root(EnumDev d, double* dst) {
     const int gl = threadIdx.x;
@@ -572,6 +646,30 @@ __global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, Pref
 
 static size_t host_rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
 
+// Number of depth-t tree nodes whose subtree meets the rank range [begin, end): the length-t
+// prefixes of the subsets begin .. end-1 are consecutive in the lexicographic order of the
+// t-subsets of {0 .. n-m+t-1}, so the count is the difference of two prefix ranks, plus one.
+static uint64_t host_prefix_rank(int n, int m, uint64_t rank, int t) {
+    // unrank the first t elements of the rank-th m-subset, accumulating their rank among t-subsets
+    uint64_t pr = 0;
+    int a = 0;
+    for (int k = 0; k < t; ++k) {
+        int j = a;
+        for (;; ++j) {
+            const uint64_t cnt = lp_host_binom(n - 1 - j, m - 1 - k);
+            if (rank < cnt) break;
+            rank -= cnt;
+            pr += lp_host_binom(n - m + t - 1 - j, t - 1 - k);  // t-prefixes starting ..j.. lie before
+        }
+        a = j + 1;
+    }
+    return pr;
+}
+static uint64_t host_level_nodes(int n, int m, uint64_t begin, uint64_t end, int t) {
+    if (end <= begin) return 0;
+    return host_prefix_rank(n, m, end - 1, t) - host_prefix_rank(n, m, begin, t) + 1;
+}
+
 bool lp_enum_prefix_supported(const lp_enum_problem* p) {
     const EnumDev& d = p->dev;
     return d.m >= 6 && d.m <= PG && (d.n - d.m) <= NMX && (d.n - d.m) >= 2;  // m - 6 >= 0 levels
@@ -586,7 +684,9 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     // default: breadth-first to depth m-6, then one lane per subset (enum_leaf.hip);
     // LP_ENUM_SWEEP=1 selects the cooperative register-resident sweep from depth m-5 instead
     const bool use_leaf = getenv("LP_ENUM_SWEEP") == nullptr;
-    const int D0 = use_leaf ? m - 6 : m - 5;
+    // (the leaf kernel performs the pivot of depth m-6 itself, so the levels stop at depth m-7)
+    const bool fused = use_leaf && m >= 7;
+    const int D0 = use_leaf ? (fused ? m - 7 : m - 6) : m - 5;
     PrefixDev& pd = p->prefix;
     // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0)
     const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
@@ -619,7 +719,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     LP_HIP(ctx, hipMemcpyAsync(d.result, p->h_result, sizeof(r), hipMemcpyHostToDevice, s));
     LP_HIP(ctx, hipMemsetAsync(pd.list_count, 0, sizeof(unsigned long long), s));
     LP_HIP(ctx, hipMemsetAsync(pd.overflow, 0, sizeof(int), s));
-    LP_HIP(ctx, hipMemsetAsync(pd.root_cursor, 0, sizeof(int), s));
+    LP_HIP(ctx, hipMemsetAsync(pd.root_cursor, 0, 2 * sizeof(int), s));
     if (getenv("LP_ENUM_DEBUG") && !pd.dbg) {
         LP_HIP(ctx, hipMalloc(&pd.dbg, 64));
     }
@@ -642,17 +742,26 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1) * sizeof(double));
         const int cap = cap64 > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)cap64;
         caps[t + 1] = cap;
-        const uint64_t bound = std::min<uint64_t>(lp_host_binom(n - m + t, t), 0x7FFFFFFFULL);
+        // parents of this level inside the range (exact; the level's holes are among them)
+        const uint64_t bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, t), 0x7FFFFFFFULL);
         const int groups_per_block = 256 / PG;
-        hipLaunchKernelGGL(k_enum_expand, (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block), 256, 0, s, d,
-                           pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
-                           (unsigned long long)begin, (unsigned long long)end);
+        // narrow levels: one wave per (parent, child)
+        const uint64_t waves = bound * (uint64_t)(n - m + 1);
+        if (waves <= (uint64_t)ctx->num_cus * 128)
+            hipLaunchKernelGGL(k_enum_expand_narrow, (unsigned)lp_ceil_div<uint64_t>(waves, 4), 256, 0, s, d, pd, t,
+                               p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
+                               (unsigned long long)begin, (unsigned long long)end);
+        else
+            hipLaunchKernelGGL(k_enum_expand, (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block), 256, 0, s,
+                               d, pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
+                               (unsigned long long)begin, (unsigned long long)end);
         ++launches;
         cur = nxt;
     }
-    const uint64_t root_bound = std::min<uint64_t>(lp_host_binom(n - m + D0, D0), 0x7FFFFFFFULL);
+    const uint64_t root_bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, D0), 0x7FFFFFFFULL);
     if (use_leaf) {
-        lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0, begin, end);
+        lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0,
+                              fused, lp_host_binom(n - m + D0 + 1, D0 + 1), begin, end);
         ++launches;
     } else {
         // two workgroups per CU are resident (<= 256 VGPRs, 52 KB LDS each); a few more than that so

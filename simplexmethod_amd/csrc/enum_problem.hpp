@@ -53,15 +53,16 @@ constexpr int kPairTabStride = 192;  // >= C(19,2)
 struct PrefixDev {
     int* level_counts;                // [32]: records of each tree level (level 0 = 1), device side
     int* overflow;                    // != 0: a buffer was too small, the caller falls back
-    int* root_cursor;                 // next depth-D0 record to be taken by a sweep group
+    int* root_cursor;                 // [2] work cursors (regular / thin leaf kernel, sweep groups)
     unsigned long long* list;         // ranks of feasible subsets
     unsigned long long* list_count;
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
     const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
-    int2* items;                      // leaf-kernel work items: (record slot, chunk of its subsets)
+    int4* items;                      // leaf-kernel work items: (record, child column, chunk, rank offset)
     int* item_count;
     int item_cap;
+    const unsigned* comb7;            // [3][36]: 7-subsets of 7, 8, 9 columns in lex order, 4 bits per index
     const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
                                       // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]
     unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
@@ -91,6 +92,7 @@ struct lp_enum_problem {
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
     unsigned* dcomb6 = nullptr;
+    unsigned* dcomb7 = nullptr;
     int* h_item_count = nullptr;               // pinned
     int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned
@@ -112,9 +114,9 @@ int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 // smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
 
-// enum_leaf.hip: one lane per subset below the depth m-6 records
-int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int nroots_bound, int root_level,
-                          uint64_t begin, uint64_t end);
+// enum_leaf.hip: one lane per subset below the records of the last breadth-first level
+int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
+                          uint64_t bound6, uint64_t begin, uint64_t end);
 
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);

@@ -51,18 +51,19 @@ def _lexrank(universe, subset):
     return r
 
 
-RECORD_COST = 26  # one depth m-6 record costs about as much as 26 subsets (measured on MI355X)
+RECORD_COST = 230  # one depth m-7 tree node costs about as much as 230 subsets (scripts/fit_cost.py, MI355X)
 
 
 def balanced_shard_bounds(n, m, rank, world, record_cost=RECORD_COST):
     """Cut [0, C(n,m)) into `world` contiguous ranges of equal estimated COST rather than equal
-    size.  The shared-prefix enumeration pays per subset and per depth m-6 tree node, and the
+    size.  The shared-prefix enumeration pays per subset and per depth m-7 tree node (its record:
+    one pivot in the last breadth-first level, two HBM round trips, one thin-kernel pass), and the
     nodes are not spread evenly along the rank axis (late prefixes have few subsets each), so
     equal-size shards differ by up to 2x in run time.  cost(x) = x + record_cost * (number of
-    depth m-6 prefixes before the x-th subset), exact combinatorics on the host.  The solver's
+    depth m-7 prefixes before the x-th subset), exact combinatorics on the host.  The solver's
     answer does not depend on where the cuts are (tie rule of SURVEY.md 8 row E1)."""
     total = _binom(n, m)
-    d0 = m - 6
+    d0 = m - 7
     if world <= 1 or d0 < 1 or total < (1 << 20):
         return shard_bounds(total, rank, world)
     universe = n - m + d0
