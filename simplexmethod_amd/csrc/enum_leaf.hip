@@ -1,24 +1,33 @@
-// enum_leaf.hip — leaf kernel of the shared-prefix enumeration: ONE LANE PER SUBSET.
+// enum_leaf.hip — leaf kernels of the shared-prefix enumeration: ONE LANE PER SUBSET.
 //
 // Input: the depth m-7 records produced breadth-first by k_enum_expand (enum_prefix.hip): the
 // tableau [W[:, c > last] | rhs] after the first m-7 Gauss-Jordan steps, shared by every subset
-// with that prefix.  A wave owns one work item (record, child column, chunk of subsets) at a
-// time: it copies the record to its private LDS slice, performs the pivot on the child column
-// cooperatively (16 rows x 4 columns per step; the depth m-6 tableau never travels through
-// HBM), and each of its 64 lanes then finishes one subset on its own: it picks
-// the remaining KD = 6 columns (lexicographic unranking of its leaf index), replays the last
-// four Gauss-Jordan steps and the 2x2 block exactly as oracle/lp_oracle.c: orc_enum_subset
-// orders them, and tests feasibility.  No cross-lane traffic, no barriers, no divergence
-// beyond the leaf loop's tail: the ~900 instructions per subset are ordinary lane-parallel
-// fp64 work, which is what this chip has in abundance (the cooperative sweep of
-// enum_prefix.hip shares two more levels but is bound by the latency of its broadcasts,
-// pivot searches and workgroup barriers).
+// with that prefix.
 //
-//   phase 1  the 6 rows not used by the prefix x the 6 chosen columns (+ rhs) sit in
-//            registers; 4 Gauss-Jordan steps with partial pivoting among the unused rows
-//            (pivot row = select chain over 6), then the 2x2 block -> x_a, x_b.
-//   phase 2  each of the m-6 rows used by the prefix streams through: 7 LDS reads, the same
-//            4 eliminations against the stored pivot rows, back-substitution, x >= -1e-9.
+// k_enum_leaves (the regular kernel, > 90 % of the subsets).  A wave owns one work item (record,
+// child column, chunk of subsets) at a time: it copies the record to its private LDS slice,
+// performs the pivot on the child column cooperatively (16 rows x 4 columns per step; the depth
+// m-6 tableau never travels through HBM), and each of its 64 lanes then finishes one subset on
+// its own: it picks the remaining 6 columns (table of all 6-subsets in lexicographic order),
+// replays the last four Gauss-Jordan steps and the 2x2 block exactly as oracle/lp_oracle.c:
+// orc_enum_subset orders them, and tests feasibility.  No cross-lane traffic, no barriers, no
+// divergence beyond the leaf loop's tail: the ~900 instructions per subset are ordinary
+// lane-parallel fp64 work, which is what this chip has in abundance (the cooperative sweep of
+// enum_prefix.hip shares two more levels but is bound by the latency of its broadcasts, pivot
+// searches and workgroup barriers).
+//
+// k_enum_thin (the tails).  A depth m-6 node with fewer than 8 selectable columns holds at most
+// C(7,6) = 7 subsets: as a work item it would cost a pivot and a wave pass for a handful of
+// lanes, and such nodes are two thirds of their level.  Their subsets are exactly the ones that
+// lie inside the LAST 8 columns of a depth m-7 node — at most C(8,7) = 8 per record — and the
+// thin kernel takes them straight from the records in HBM: 8 lanes per record, 7 columns per
+// lane, every lane reading its own record (no LDS staging, nothing wave-uniform).
+//
+//   phase 1  the KD rows not used by the prefix x the KD chosen columns (+ rhs) sit in
+//            registers; KD-2 Gauss-Jordan steps with partial pivoting among the unused rows
+//            (pivot row = select chain), then the 2x2 block -> x_a, x_b.
+//   phase 2  each of the m-KD rows used by the prefix streams through: KD+1 reads, the same
+//            eliminations against the stored pivot rows, back-substitution, x >= -1e-9.
 #include "enum_tree.hpp"
 
 using namespace lptree;
@@ -27,9 +36,147 @@ namespace {
 
 constexpr int LEAF_THREADS = 256;
 constexpr int LEAF_WAVES = LEAF_THREADS / 64;
-constexpr int THIN_TAIL = 9;          // the thin kernel takes the subsets inside the last 9 columns
+constexpr int THIN_TAIL = 8;          // the thin kernel takes the subsets inside the last 8 columns
 constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
                                       // same row of different columns hit different banks
+
+// One subset, one lane.  tab: the node's tableau, column q (stride STRIDE doubles) = the q-th
+// selectable column, column R = the rhs; c[]: the KD chosen columns; U[]: the KD rows not used by
+// the prefix, ascending; used: mask of the rows the prefix did use.  UNIFORM: tab / U / used are
+// the same in every lane of the wave (the phase 2 loop then runs on scalar registers).
+// Returns 0 feasible, 1 infeasible, 2 singular.
+template <int KD, int STRIDE, bool UNIFORM>
+__device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
+                                            unsigned used, double minp0, double maxp0, int m) {
+    // ---- phase 1: unused rows x chosen columns
+    double E[KD][KD], H[KD];
+#pragma unroll
+    for (int r = 0; r < KD; ++r) {
+#pragma unroll
+        for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * STRIDE + U[r]];
+        H[r] = tab[R * STRIDE + U[r]];
+    }
+    // Invariant: before step t, rows t..KD-1 of E are the rows not yet used, in ascending
+    // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
+    // are the pivot rows of steps 0..t-1.  The chosen row p is ROTATED into position t
+    // (rows t..p-1 move down by one): afterwards every access below has a static index —
+    // no per-element "is this the pivot row" selects, and the 2x2 block is the last two rows.
+    double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
+    double minp = minp0, maxp = maxp0;
+    bool sing = false;
+#pragma unroll
+    for (int t = 0; t < KD - 2; ++t) {
+        double big = -1.0, piv = 0.0;
+        int p = t;
+#pragma unroll
+        for (int r = t; r < KD; ++r) {
+            const double a = fabs(E[r][t]);
+            const bool take = a > big;   // strict: ties keep the first (lowest) row
+            big = take ? a : big;
+            piv = take ? E[r][t] : piv;
+            p = take ? r : p;
+        }
+        if (!(big > 0.0)) sing = true;
+        minp = fmin(minp, big);
+        maxp = fmax(maxp, big);
+        const double inv = 1.0 / piv;
+        INV[t] = inv;
+        // rotate row p to position t (columns t..KD-1 and the rhs)
+#pragma unroll
+        for (int cc = t; cc <= KD; ++cc) {
+            double pr = (cc < KD) ? E[t][cc < KD ? cc : 0] : H[t];
+#pragma unroll
+            for (int r = t + 1; r < KD; ++r) {
+                const double v = (cc < KD) ? E[r][cc < KD ? cc : 0] : H[r];
+                pr = (r == p) ? v : pr;
+            }
+#pragma unroll
+            for (int r = KD - 1; r > t; --r) {
+                if (cc < KD)
+                    E[r][cc < KD ? cc : 0] = (r <= p) ? E[r - 1][cc < KD ? cc : 0] : E[r][cc < KD ? cc : 0];
+                else
+                    H[r] = (r <= p) ? H[r - 1] : H[r];
+            }
+            if (cc < KD) E[t][cc < KD ? cc : 0] = pr; else H[t] = pr;
+        }
+#pragma unroll
+        for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
+        PRH[t] = H[t];
+#pragma unroll
+        for (int r = 0; r < KD; ++r) {
+            if (r == t) continue;
+            const double lx = -(E[r][t] * inv);
+#pragma unroll
+            for (int cc = t + 1; cc < KD; ++cc) E[r][cc] = fma(lx, PR[t][cc], E[r][cc]);
+            H[r] = fma(lx, PRH[t], H[r]);
+        }
+#pragma unroll
+        for (int cc = t + 1; cc < KD; ++cc) E[t][cc] = PR[t][cc] * inv;
+        H[t] = PRH[t] * inv;
+    }
+    // ---- 2x2 block on the two rows still unused and the last two chosen columns
+    const double a1 = E[KD - 2][KD - 2], a2 = E[KD - 1][KD - 2], b1 = E[KD - 2][KD - 1],
+                 b2 = E[KD - 1][KD - 1], h1 = H[KD - 2], h2 = H[KD - 1];
+    const bool second = fabs(a2) > fabs(a1);
+    const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
+    const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
+    const double big1 = fabs(pa);
+    const double inv1 = 1.0 / pa;
+    const double l = -(qa * inv1);
+    const double wqb = fma(l, pb, qb);
+    const double rq = fma(l, ph, qh);
+    const double big2 = fabs(wqb);
+    const double inv2 = 1.0 / wqb;
+    const double xb = rq * inv2;
+    const double xa = fma(-pb, xb, ph) * inv1;
+    if (!(big1 > 0.0) || !(big2 > 0.0)) sing = true;
+    minp = fmin(minp, fmin(big1, big2));
+    maxp = fmax(maxp, fmax(big1, big2));
+    if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
+    bool feas = (xa >= -1e-9) && (xb >= -1e-9);
+    // the rows pivoted in phase 1: back-substitution
+#pragma unroll
+    for (int r = 0; r < KD - 2; ++r) {
+        const double x = fma(-E[r][KD - 1], xb, fma(-E[r][KD - 2], xa, H[r]));
+        feas = feas && (x >= -1e-9);
+    }
+    // ---- phase 2: rows already used by the prefix, one at a time
+    // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
+    // after a row or two: it stops as soon as no lane of the wave is still feasible)
+    bool alive = !sing && feas;
+    unsigned rows = used & ((1u << m) - 1u);
+    auto one_row = [&](int i, bool has) {
+        double v[KD];
+#pragma unroll
+        for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * STRIDE + i];
+        double h = tab[R * STRIDE + i];
+#pragma unroll
+        for (int t = 0; t < KD - 2; ++t) {
+            const double lx = -(v[t] * INV[t]);
+#pragma unroll
+            for (int cc = t + 1; cc < KD; ++cc) v[cc] = fma(lx, PR[t][cc], v[cc]);
+            h = fma(lx, PRH[t], h);
+        }
+        const double x = fma(-v[KD - 1], xb, fma(-v[KD - 2], xa, h));
+        feas = feas && (!has || x >= -1e-9);
+        alive = alive && feas;
+    };
+    if constexpr (UNIFORM) {
+        while (rows && __any(alive)) {
+            const int i = __builtin_ctz(rows);
+            rows &= rows - 1u;
+            one_row(i, true);
+        }
+    } else {
+        while (__any(alive && rows != 0u)) {
+            const bool has = rows != 0u;
+            const int i = has ? __builtin_ctz(rows) : 0;
+            rows &= rows - 1u;
+            one_row(i, has);
+        }
+    }
+    return sing ? 2 : (feas ? 0 : 1);
+}
 
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
 
@@ -101,25 +248,16 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
     });
 }
 
-// KD = columns chosen per lane.
-//   <6, false, true>   the regular kernel: work items (record, child, chunk) over the depth m-7
-//                      records; the wave pivots on the child column itself (FUSED), the lanes take
-//                      the 6 remaining columns.
-//   <7, true, false>   "thin": over the same depth m-7 records, it takes exactly the subsets that
-//                      lie inside the last THIN_TAIL = 9 selectable columns — the ones whose depth
-//                      m-6 node would hold fewer than 29 subsets.  Those nodes are 78 % of their
-//                      level but carry 6 % of the subsets; each would cost a pivot and a nearly
-//                      empty wave pass.
-//   <6, false, false>  m = 6: the root record is the depth m-6 node.
-template <int KD, bool THIN, bool FUSED>
-__global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(KD == 6 ? 3 : 2)))
-void k_enum_leaves(EnumDev d, PrefixDev pd,
-                                                              const double* __restrict__ roots,
-                                                              int root_level, int root_cap,
-                                                              unsigned long long begin,
-                                                              unsigned long long end) {
+// FUSED: work items (record, child, chunk) over the depth m-7 records; the wave pivots on the
+// child column itself, the lanes take the 6 remaining columns.  !FUSED (m = 6): the root record
+// is the depth m-6 node.
+template <bool FUSED>
+__global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
+void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, unsigned long long begin,
+                   unsigned long long end) {
+    constexpr int KD = 6;
     constexpr int MAXCOLS = NMX + KD + 1 + (FUSED ? 1 : 0);  // columns of a record (+ rhs)
-    constexpr int CHILDCOLS = NMX + KD + 1;                  // columns of a depth m-KD tableau (+ rhs)
+    constexpr int CHILDCOLS = NMX + KD + 1;                  // columns of a depth m-6 tableau (+ rhs)
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
     __shared__ __attribute__((aligned(16))) double s_child[FUSED ? LEAF_WAVES : 1][FUSED ? CHILDCOLS * TS : 1];
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
@@ -127,33 +265,31 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
     const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
-    const int nitems = THIN ? min(pd.level_counts[root_level], root_cap)
-                            : min(*pd.item_count, pd.item_cap);   // built by k_enum_make_items
-    int* const cursor = pd.root_cursor + (THIN ? 1 : 0);
+    const int nitems = min(*pd.item_count, pd.item_cap);        // built by k_enum_make_items
+    int* const cursor = pd.root_cursor;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
-    if (tid < 32) s_off[tid] = THIN ? 0u : pd.comb6[tid];
+    if (tid < 32) s_off[tid] = pd.comb6[tid];
     __syncthreads();
     unsigned int cntF = 0, cntI = 0, cntS = 0;
 
-    // Software pipeline over work items (record, chunk): while item A is computed from LDS slice
-    // `buf`, the whole record of item B (its index was drawn one iteration earlier) is in flight
-    // into registers, and the index of item C is being drawn — neither the atomic nor the HBM
-    // round trip of a record sits between two items.
+    // Software pipeline over work items: while item A is computed from LDS slice `buf`, the whole
+    // record of item B (its index was drawn one iteration earlier) is in flight into registers,
+    // and the index of item C is being drawn — neither the atomic nor the HBM round trip of a
+    // record sits between two items.
     constexpr int NLOAD = (MAXCOLS * PG + 63) / 64;   // doubles per lane to hold one record
     const int rec_cols = n - D + 1;                   // columns of a record incl. rhs
     // Items are dealt in runs: one returning atomic on a single word costs ~11 ns chip-wide, which
-    // at one draw per item would bound the whole kernel (2 M records for C(32,16) in the thin one).
-    // The first deal is static — wave w owns items [w*k0, (w+1)*k0) — so that the launch does not
-    // open with two atomics per wave on that word (~0.2 ms for a full grid); later runs shrink with
-    // what is left (guided self-scheduling: a wave holding a long run while the others have
-    // finished is the kernel's tail), and a wave whose last run reached the end of the table does
-    // not ask again.
-    constexpr int kMaxRun = THIN ? 16 : 4;
+    // at one draw per item could bound the whole kernel.  The first deal is static — wave w owns
+    // items [w*k0, (w+1)*k0) — so that the launch does not open with two atomics per wave on that
+    // word (~0.2 ms for a full grid); later runs shrink with what is left (guided self-scheduling:
+    // a wave holding a long run while the others have finished is the kernel's tail), and a wave
+    // whose last run reached the end of the table does not ask again.
+    constexpr int kMaxRun = 4;
     const int nwaves = (int)gridDim.x * LEAF_WAVES;
     const int k0 = max(1, min(kMaxRun, nitems / (nwaves * 4)));
     const int dyn_base = nwaves * k0;
@@ -174,15 +310,11 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
     NodeMeta pmB;
     int chunkB = 0, childB = 0, roffB = 0;
     auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
-        int rec = item;
-        if (!THIN) {
-            const int4 it = pd.items[item];
-            rec = it.x;
-            childB = it.y;
-            chunkB = it.z;
-            roffB = it.w;
-        }
-        const double* Q = roots + (size_t)rec * rec_doubles(n, D);
+        const int4 it = pd.items[item];
+        childB = it.y;
+        chunkB = it.z;
+        roffB = it.w;
+        const double* Q = roots + (size_t)it.x * rec_doubles(n, D);
 #pragma unroll
         for (int q = 0; q < NLOAD; ++q) {
             const int k = lane + 64 * q;
@@ -210,18 +342,16 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
         itemC = draw();
         if (itemB < nitems) fetch(itemB);
         if (pm.last_col == kHole) continue;
-        const int last = FUSED ? child : pm.last_col;  // last chosen column of the depth m-KD node
+        const int last = FUSED ? child : pm.last_col;  // last chosen column of the depth m-6 node
         const int R = n - 1 - last;                    // selectable columns
         if (R < KD) continue;
-        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, KD) subsets below this node
-        // subset table: all KD-subsets in lexicographic order, packed (5 or 4 bits per index)
-        const int R9 = R < THIN_TAIL ? R : THIN_TAIL;
-        const unsigned* comb = THIN ? pd.comb7 + 36 * (R9 - 7) : pd.comb6 + s_off[R];
-        const unsigned int tail = THIN ? s_binom[R9 * (KD + 1) + KD] : 0u;  // C(min(R,9), 7)
+        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, 6) subsets below this node
+        // subset table: all 6-subsets of R columns in lexicographic order, 5 bits per index
+        // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
+        const unsigned* comb = pd.comb6 + s_off[R];
         const unsigned long long rb = pm.rank_base + (unsigned long long)(FUSED ? roff : 0);
-        // thin: the last `tail` subsets of the node (those inside its last 9 columns)
-        const unsigned int leaf_lo = THIN ? L - tail : (unsigned int)chunk * kChunk;
-        const unsigned int leaf_hi = THIN ? L : ((leaf_lo + kChunk < L) ? leaf_lo + kChunk : L);
+        const unsigned int leaf_lo = (unsigned int)chunk * kChunk;
+        const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
         double minp0 = pm.minp, maxp0 = pm.maxp;
         unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
         if (FUSED) {
@@ -257,7 +387,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
         } else {
             tab += (last + 1 - D) * TS;              // column q below = column last+1+q
         }
-        // rows: the KD not used by the prefix (ascending), and the used ones
+        // rows: the 6 not used by the prefix (ascending), and the used ones
         int U[KD];
         {
             unsigned free_rows = ~umask & ((1u << m) - 1u);
@@ -267,142 +397,17 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
                 free_rows &= free_rows - 1u;
             }
         }
-
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
             if (rank < begin || rank >= end) continue;
-            // ---- the leaf's 6 columns: table of all 6-subsets of R columns in lexicographic order
-            // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
             int c[KD];
-            if (THIN) {
-                const unsigned pk = comb[leaf - leaf_lo];
+            const unsigned pk = comb[leaf];
 #pragma unroll
-                for (int t = 0; t < KD; ++t) c[t] = (R - R9) + (int)((pk >> (4 * t)) & 15u);
-            } else {
-                const unsigned pk = comb[leaf];
-#pragma unroll
-                for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
-            }
-            // ---- phase 1: unused rows x chosen columns
-            double E[KD][KD], H[KD];
-#pragma unroll
-            for (int r = 0; r < KD; ++r) {
-#pragma unroll
-                for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * TS + U[r]];
-                H[r] = tab[R * TS + U[r]];
-            }
-            // Invariant: before step t, rows t..5 of E are the rows not yet used, in ascending
-            // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
-            // are the pivot rows of steps 0..t-1.  The chosen row p is ROTATED into position t
-            // (rows t..p-1 move down by one): afterwards every access below has a static index —
-            // no per-element "is this the pivot row" selects, and the 2x2 block is rows 4 and 5.
-            double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
-            double minp = minp0, maxp = maxp0;
-            bool sing = false;
-#pragma unroll
-            for (int t = 0; t < KD - 2; ++t) {
-                double big = -1.0, piv = 0.0;
-                int p = t;
-#pragma unroll
-                for (int r = t; r < KD; ++r) {
-                    const double a = fabs(E[r][t]);
-                    const bool take = a > big;   // strict: ties keep the first (lowest) row
-                    big = take ? a : big;
-                    piv = take ? E[r][t] : piv;
-                    p = take ? r : p;
-                }
-                if (!(big > 0.0)) sing = true;
-                minp = fmin(minp, big);
-                maxp = fmax(maxp, big);
-                const double inv = 1.0 / piv;
-                INV[t] = inv;
-                // rotate row p to position t (columns t..5 and the rhs)
-#pragma unroll
-                for (int cc = t; cc <= KD; ++cc) {
-                    double pr = (cc < KD) ? E[t][cc < KD ? cc : 0] : H[t];
-#pragma unroll
-                    for (int r = t + 1; r < KD; ++r) {
-                        const double v = (cc < KD) ? E[r][cc < KD ? cc : 0] : H[r];
-                        pr = (r == p) ? v : pr;
-                    }
-#pragma unroll
-                    for (int r = KD - 1; r > t; --r) {
-                        if (cc < KD)
-                            E[r][cc < KD ? cc : 0] = (r <= p) ? E[r - 1][cc < KD ? cc : 0] : E[r][cc < KD ? cc : 0];
-                        else
-                            H[r] = (r <= p) ? H[r - 1] : H[r];
-                    }
-                    if (cc < KD) E[t][cc < KD ? cc : 0] = pr; else H[t] = pr;
-                }
-#pragma unroll
-                for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
-                PRH[t] = H[t];
-#pragma unroll
-                for (int r = 0; r < KD; ++r) {
-                    if (r == t) continue;
-                    const double lx = -(E[r][t] * inv);
-#pragma unroll
-                    for (int cc = t + 1; cc < KD; ++cc) E[r][cc] = fma(lx, PR[t][cc], E[r][cc]);
-                    H[r] = fma(lx, PRH[t], H[r]);
-                }
-#pragma unroll
-                for (int cc = t + 1; cc < KD; ++cc) E[t][cc] = PR[t][cc] * inv;
-                H[t] = PRH[t] * inv;
-            }
-            // ---- 2x2 block on the two rows still unused (rows 4 < 5) and columns c[4], c[5]
-            const double a1 = E[KD - 2][KD - 2], a2 = E[KD - 1][KD - 2], b1 = E[KD - 2][KD - 1],
-                         b2 = E[KD - 1][KD - 1], h1 = H[KD - 2], h2 = H[KD - 1];
-            const bool second = fabs(a2) > fabs(a1);
-            const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
-            const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
-            const double big1 = fabs(pa);
-            const double inv1 = 1.0 / pa;
-            const double l = -(qa * inv1);
-            const double wqb = fma(l, pb, qb);
-            const double rq = fma(l, ph, qh);
-            const double big2 = fabs(wqb);
-            const double inv2 = 1.0 / wqb;
-            const double xb = rq * inv2;
-            const double xa = fma(-pb, xb, ph) * inv1;
-            if (!(big1 > 0.0) || !(big2 > 0.0)) sing = true;
-            minp = fmin(minp, fmin(big1, big2));
-            maxp = fmax(maxp, fmax(big1, big2));
-            if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
-            bool feas = (xa >= -1e-9) && (xb >= -1e-9);
-            // the four rows pivoted in phase 1: back-substitution
-#pragma unroll
-            for (int r = 0; r < KD - 2; ++r) {
-                const double x = fma(-E[r][KD - 1], xb, fma(-E[r][KD - 2], xa, H[r]));
-                feas = feas && (x >= -1e-9);
-            }
-            // ---- phase 2: rows already used by the prefix, one at a time
-            // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
-            // after a row or two: it stops as soon as no lane of the wave is still feasible)
-            bool alive = !sing && feas;
-            {
-                unsigned rows = umask & ((1u << m) - 1u);
-                while (rows && __any(alive)) {
-                    const int i = __builtin_ctz(rows);
-                    rows &= rows - 1u;
-                    double v[KD];
-#pragma unroll
-                    for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * TS + i];
-                    double h = tab[R * TS + i];
-#pragma unroll
-                    for (int t = 0; t < KD - 2; ++t) {
-                        const double lx = -(v[t] * INV[t]);
-#pragma unroll
-                        for (int cc = t + 1; cc < KD; ++cc) v[cc] = fma(lx, PR[t][cc], v[cc]);
-                        h = fma(lx, PRH[t], h);
-                    }
-                    const double x = fma(-v[KD - 1], xb, fma(-v[KD - 2], xa, h));
-                    feas = feas && (x >= -1e-9);
-                    alive = alive && feas;
-                }
-            }
-            if (sing) {
+            for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
+            const int verdict = leaf_verdict<KD, TS, true>(tab, c, R, U, umask, minp0, maxp0, m);
+            if (verdict == 2) {
                 ++cntS;
-            } else if (!feas) {
+            } else if (verdict == 1) {
                 ++cntI;
             } else {
                 ++cntF;
@@ -414,6 +419,67 @@ void k_enum_leaves(EnumDev d, PrefixDev pd,
     if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
     if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
     if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
+    __syncthreads();
+    if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
+}
+
+// The tails: 8 lanes per depth m-7 record, lane j takes the j-th 7-subset (lexicographic) of the
+// record's last min(R, 8) selectable columns — C(8,7) = 8, C(7,7) = 1 — reading the record where
+// it lies in HBM (column stride PG).
+__global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev pd,
+                                                             const double* __restrict__ roots,
+                                                             int root_level, int root_cap,
+                                                             unsigned long long begin,
+                                                             unsigned long long end) {
+    constexpr int KD = 7;
+    __shared__ unsigned long long s_cnt[3];
+    const int m = d.m, n = d.n, D = m - KD;
+    const int nrec = min(pd.level_counts[root_level], root_cap);
+    const int tid = threadIdx.x;
+    if (tid < 3) s_cnt[tid] = 0ULL;
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * LEAF_THREADS + tid;
+    const int rec = (int)(gid >> 3), j = (int)(gid & 7);
+    int verdict = -1;
+    unsigned long long rank = 0ULL;
+    if (rec < nrec) {
+        const double* Q = roots + (size_t)rec * rec_doubles(n, D);
+        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(Q + (size_t)PG * (n - D + 1));
+        const int last = pm->last_col;
+        const int R = n - 1 - last;
+        const int R8 = R < THIN_TAIL ? R : THIN_TAIL;
+        // the 7-subsets of 8 columns in lexicographic order: the j-th leaves out column 7 - j
+        const int ntail = (R8 == THIN_TAIL) ? THIN_TAIL : 1;
+        if (last != kHole && R >= KD && j < ntail) {
+            // L - ntail + j: the tail subsets are the last ones of the node
+            rank = pm->rank_base + (binom(d, R, KD) - (unsigned long long)ntail + (unsigned long long)j);
+            if (rank >= begin && rank < end) {
+                int c[KD];
+#pragma unroll
+                for (int t = 0; t < KD; ++t) c[t] = (R - R8) + t + ((R8 == THIN_TAIL && t >= 7 - j) ? 1 : 0);
+                const unsigned umask = pm->used_mask;
+                int U[KD];
+                unsigned free_rows = ~umask & ((1u << m) - 1u);
+#pragma unroll
+                for (int r = 0; r < KD; ++r) {
+                    U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
+                    free_rows &= free_rows - 1u;
+                }
+                const double* tab = Q + (size_t)(last + 1 - D) * PG;   // column q = column last+1+q
+                verdict = leaf_verdict<KD, PG, false>(tab, c, R, U, umask, pm->minp, pm->maxp, m);
+            }
+        }
+    }
+    if (verdict == 0) {
+        const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+        if (at < pd.list_cap) pd.list[at] = rank;
+    }
+    // counts: one atomic per wave and verdict
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const unsigned long long bal = __ballot(verdict == v);
+        if ((tid & 63) == 0 && bal) atomicAdd(&s_cnt[v], (unsigned long long)__popcll(bal));
+    }
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
 }
@@ -439,20 +505,18 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     }
     LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, sizeof(int), ctx->stream));
     // persistent waves (items are dealt dynamically): as many blocks as are resident
-    const int grid6 = ctx->num_cus * 3, grid7 = ctx->num_cus * 2;
+    const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
     if (fused) {
         hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, THIN_TAIL, b, e);
-        hipLaunchKernelGGL((k_enum_leaves<6, false, true>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, b, e);
-        hipLaunchKernelGGL((k_enum_leaves<7, true, false>), grid7, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<true>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        hipLaunchKernelGGL(k_enum_thin, (unsigned)lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS),
+                           LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, b, e);
-        hipLaunchKernelGGL((k_enum_leaves<6, false, false>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<false>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
     }
     return LP_OPTIMAL;
 }
