@@ -120,6 +120,25 @@ int lp_simplex_download(lp_simplex_problem* p, double* x_out, int* basis_out, do
                         int* trace_enter, int* trace_leave, int trace_cap, double* tableau_out);
 void lp_simplex_free(lp_simplex_problem* p);
 
+/* ---- Two-phase simplex ---------------------------------------
+ * For canonical problems without a usable starting basis (Symmetrical min problems,
+ * negative b).  Replaces the flow the reference sketches in code its public API cannot reach
+ * (SimplexSolover.h:61-68 make_b_nonneg, :70-95 createAuxiliaryProblem, :331-381
+ * replaceArtificialColumns, :383-406 twoPhaseSimplex), made consistent: rows with b < -eps
+ * change sign; phase I minimises the sum of m artificials [A' | I] from their identity basis;
+ * LP_INFEASIBLE iff that sum > eps; an artificial still basic leaves for the first non-basic
+ * original column with |T[pos][cand]| > eps (none: LP_SINGULAR, dependent constraints); phase II
+ * = lp_simplex_solve on (A', b', c) from the clean basis.  Every pivot runs on the GPU.
+ * iters_out (optional): 3 ints = pivots of phase I, drive-out pivots, pivots of phase II.       */
+int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const double* b,
+                         const double* c, int maximize, int n_orig, double eps, int max_iter,
+                         double* x_out, int* basis_out, double* obj_out, int* iters_out);
+/* Row `row` (0..m-1 by basis position, m = reduced costs) of the current tableau: n+1 doubles. */
+int lp_simplex_row(lp_simplex_problem* p, int row, double* out);
+/* One Gauss-Jordan pivot at (row, col) of the current tableau, chosen by the caller
+ * (replaceArtificialColumns, :357-366: N(pos) = cand; Binv = F * Binv).                        */
+int lp_simplex_force_pivot(lp_simplex_problem* p, int row, int col);
+
 /* Times `iters` launches of the rank-1 update kernel alone on the problem's
  * current tableau (pivot element (row, col) must be non-zero; the tableau is
  * restored afterwards).  ms_per_launch = HIP-event time / iters.                  */

@@ -511,6 +511,70 @@ int orc_simplex_tableau(const double* A, int m, int n, const double* b, const do
 }
 
 /* ------------------------------------------------------------------------- */
+/* two-phase simplex — the flow the reference sketches in its */
+/* unreachable code (SimplexSolover.h:61-95 make_b_nonneg/createAuxiliaryProblem, */
+/* :331-381 replaceArtificialColumns, :383-406 twoPhaseSimplex), made consistent */
+/* and built from the tableau simplex above.  Build-defined, parity unpinned.   */
+/* ------------------------------------------------------------------------- */
+int orc_two_phase(const double* A, int m, int n, const double* b, const double* c, int maximize,
+                  int n_orig, double eps, int max_iter, double* x_out, int* basis_out,
+                  double* obj_out, int* iters_out /* 3: phase I, drive-out, phase II */) {
+    if (m <= 0 || n < m || !A || !b || !c || !x_out) return ORC_BAD_ARG;
+    if (n_orig <= 0 || n_orig > n) return ORC_BAD_ARG;
+    const int na = n + m;
+    double* A1 = (double*)xmalloc(sizeof(double) * (size_t)m * na); /* [A' | I], column-major */
+    double* b1 = (double*)xmalloc(sizeof(double) * (size_t)m);
+    double* c1 = (double*)xmalloc(sizeof(double) * (size_t)na);
+    double* xa = (double*)xmalloc(sizeof(double) * (size_t)na);
+    int* N = (int*)xmalloc(sizeof(int) * (size_t)m);
+    double* T = (double*)xmalloc(sizeof(double) * (size_t)(m + 1) * (na + 1));
+    int it[3] = {0, 0, 0};
+    /* make_b_nonneg, :61-68: rows with b < -EPS change sign */
+    for (int i = 0; i < m; ++i) {
+        const int flip = b[i] < -eps;
+        b1[i] = flip ? -b[i] : b[i];
+        for (int j = 0; j < n; ++j) A1[(size_t)j * m + i] = flip ? -AT(A, m, i, j) : AT(A, m, i, j);
+        for (int j = 0; j < m; ++j) A1[(size_t)(n + j) * m + i] = (i == j) ? 1.0 : 0.0;
+    }
+    /* createAuxiliaryProblem, :70-95: minimise the sum of the artificials from their basis */
+    for (int j = 0; j < na; ++j) c1[j] = (j < n) ? 0.0 : 1.0;
+    for (int t = 0; t < m; ++t) N[t] = n + t;
+    int status = orc_simplex_tableau(A1, m, na, b1, c1, N, 0, na, eps, max_iter, xa, N, NULL, &it[0],
+                                     NULL, NULL, 0, T);
+    if (status == ORC_OPTIMAL) {
+        double sum = 0.0; /* :347-350 */
+        for (int i = 0; i < m; ++i) sum += xa[n + i];
+        if (sum > eps) status = ORC_INFEASIBLE; /* :352-353 */
+    }
+    if (status == ORC_OPTIMAL) {
+        /* replaceArtificialColumns, :331-381: an artificial still basic (at level 0) leaves for the
+         * first non-basic original column with |T[pos][cand]| > EPS; none = dependent rows        */
+        const int ld = na + 1;
+        unsigned char* basic = (unsigned char*)xmalloc((size_t)na);
+        for (int pos = 0; pos < m && status == ORC_OPTIMAL; ++pos) {
+            if (N[pos] < n) continue;
+            memset(basic, 0, (size_t)na);
+            for (int t = 0; t < m; ++t) basic[N[t]] = 1;
+            int cand = -1;
+            for (int j = 0; j < n; ++j)
+                if (!basic[j] && fabs(T[(size_t)pos * ld + j]) > eps) { cand = j; break; }
+            if (cand < 0) { status = ORC_SINGULAR; break; } /* :372-380 */
+            tableau_pivot(T, m + 1, na + 1, ld, pos, cand);
+            N[pos] = cand;
+            ++it[1];
+        }
+        free(basic);
+    }
+    if (status == ORC_OPTIMAL) /* phase II from the clean basis, :383-404 */
+        status = orc_simplex_tableau(A1, m, n, b1, c, N, maximize, n_orig, eps, max_iter, x_out, N,
+                                     obj_out, &it[2], NULL, NULL, 0, NULL);
+    if (basis_out) memcpy(basis_out, N, sizeof(int) * (size_t)m);
+    if (iters_out) memcpy(iters_out, it, sizeof(it));
+    free(T); free(N); free(xa); free(c1); free(b1); free(A1);
+    return status;
+}
+
+/* ------------------------------------------------------------------------- */
 /* per-basis solve — Canonical.cpp:165-197 (ColPivHouseholderQR restated)    */
 /* ------------------------------------------------------------------------- */
 

@@ -75,6 +75,19 @@ int orc_simplex_tableau(const double* A, int m, int n, const double* b, const do
                         int* trace_enter, int* trace_leave, int trace_cap,
                         double* tableau_out);
 
+/* ---- Two-phase simplex (build-defined, parity unpinned) -----------
+ * For canonical problems without a usable starting basis (Symmetrical min problems, negative
+ * b).  Flow of the reference's unreachable sketch (SimplexSolover.h:61-95, :331-406), made
+ * consistent: rows with b < -eps change sign; phase I minimises the sum of m artificials
+ * [A' | I] from their identity basis with the tableau simplex above; infeasible iff that sum
+ * > eps; an artificial still basic is pivoted out on the first non-basic original column with
+ * |T[pos][cand]| > eps (none: ORC_SINGULAR, dependent rows); phase II = orc_simplex_tableau on
+ * (A', b', c) from the clean basis.  iters_out[3] = pivots of phase I, drive-out, phase II.
+ */
+int orc_two_phase(const double* A, int m, int n, const double* b, const double* c, int maximize,
+                  int n_orig, double eps, int max_iter, double* x_out, int* basis_out,
+                  double* obj_out, int* iters_out);
+
 /* One sequential "chain" selection as written at SimplexSolover.h:153-161
  * (maximize: take j if d > best + eps) / :164-172 (minimize) / :181-192 (ratio
  * test = minimize flavour).  mask[j] != 0 marks eligible entries.  Returns the

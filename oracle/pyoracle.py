@@ -46,6 +46,9 @@ def lib():
         L.orc_simplex_tableau.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, _ip, C.c_int, C.c_int,
                                           C.c_double, C.c_int, _dp, _ip, _dp, _ip, _ip, _ip, C.c_int,
                                           _dp]
+        L.orc_two_phase.restype = C.c_int
+        L.orc_two_phase.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double,
+                                    C.c_int, _dp, _ip, _dp, _ip]
         L.orc_chain_select.restype = C.c_int
         L.orc_chain_select.argtypes = [_dp, C.c_char_p, C.c_int, C.c_int, C.c_double, _dp]
         L.orc_basic_solution.restype = C.c_int
@@ -147,6 +150,21 @@ def simplex_tableau(A, b, c, basis, maximize=True, n_orig=None, eps=1e-9, max_it
     n_orig = A.shape[1] if n_orig is None else n_orig
     return _simplex("tableau", A, b, c, basis, maximize, n_orig, eps, max_iter, trace_cap,
                     want_tableau)
+
+
+def two_phase(A, b, c, maximize=False, n_orig=None, eps=1e-9, max_iter=10000):
+    """orc_two_phase: no starting basis needed."""
+    A = np.asarray(A, dtype=np.float64)
+    m, n = A.shape
+    n_orig = n if n_orig is None else n_orig
+    Af, b, c = _colmajor(A), _f64(b), _f64(c)
+    x = np.zeros(n_orig)
+    basis_out = np.full(m, -1, dtype=np.int32)
+    obj = C.c_double(float("nan"))
+    iters = np.zeros(3, dtype=np.int32)
+    st = lib().orc_two_phase(_d(Af), m, n, _d(b), _d(c), int(maximize), n_orig, eps, max_iter,
+                             _d(x), _i(basis_out), C.byref(obj), _i(iters))
+    return dict(status=st, x=x, basis=basis_out, obj=obj.value, iters=iters.tolist())
 
 
 def chain_select(v, mask=None, want_max=True, eps=1e-9):

@@ -55,6 +55,10 @@ SIGNATURES = {
     "lp_simplex_profile": (C.c_int, [_vp, C.c_int]),
     "lp_simplex_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip, C.c_int, _dp]),
     "lp_simplex_free": (None, [_vp]),
+    "lp_simplex_two_phase": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int,
+                                       C.c_double, C.c_int, _dp, _ip, _dp, _ip]),
+    "lp_simplex_row": (C.c_int, [_vp, C.c_int, _dp]),
+    "lp_simplex_force_pivot": (C.c_int, [_vp, C.c_int, C.c_int]),
     "lp_bench_rank1_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp]),
     "lp_bench_rankj_update": (C.c_int, [_vp, C.c_int, _fp, _ip]),
     "lp_debug_simplex_stamps": (C.c_int, [_vp, C.c_int, _u64p]),
@@ -210,6 +214,21 @@ class Context:
                                                   _i(bo), C.byref(obj), C.byref(it)))
         return dict(status=rc, x=x[:n_orig], basis=bo, obj=obj.value, iters=it.value)
 
+    def two_phase(self, A, b, c, maximize=False, n_orig=None, eps=EPS, max_iter=MAX_ITER):
+        """lp_simplex_two_phase: no starting basis needed."""
+        A = np.asarray(A, dtype=np.float64)
+        m, n = A.shape
+        n_orig = n if n_orig is None else n_orig
+        Af, b, c = colmajor(A), _f64(b), _f64(c)
+        x = np.zeros(n_orig)
+        bo = np.full(m, -1, dtype=np.int32)
+        obj = C.c_double(float("nan"))
+        it = np.zeros(3, dtype=np.int32)
+        rc = self.check(self.lib.lp_simplex_two_phase(self.h, _d(Af), m, n, _d(b), _d(c),
+                                                      int(maximize), n_orig, eps, max_iter, _d(x),
+                                                      _i(bo), C.byref(obj), _i(it)))
+        return dict(status=rc, x=x, basis=bo, obj=obj.value, iters=it.tolist())
+
     def simplex_problem(self, A, b, c, basis, maximize=True, n_orig=None):
         return SimplexProblem(self, A, b, c, basis, maximize, n_orig)
 
@@ -293,6 +312,15 @@ class SimplexProblem:
                                                         _i(tl), trace_cap, _d(tab)))
         return dict(x=x, basis=bo, obj=obj.value, trace_enter=te[:trace_cap],
                     trace_leave=tl[:trace_cap], tableau=tab)
+
+    def row(self, row):
+        """Row `row` of the current tableau (m = reduced costs): n + 1 doubles."""
+        out = np.zeros(self.n + 1)
+        self.ctx.check(self.ctx.lib.lp_simplex_row(self.h, int(row), _d(out)))
+        return out
+
+    def force_pivot(self, row, col):
+        return self.ctx.check(self.ctx.lib.lp_simplex_force_pivot(self.h, int(row), int(col)))
 
     def bench_update(self, row, col, iters):
         ms = C.c_float(0.0)

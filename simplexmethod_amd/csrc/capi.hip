@@ -347,6 +347,100 @@ int lp_simplex_solve(lp_context* ctx, const double* A, int m, int n, const doubl
     return rc;
 }
 
+int lp_simplex_row(lp_simplex_problem* p, int row, double* out) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    if (!out || row < 0 || row > p->dev.m) LP_FAIL(ctx, LP_BAD_ARG, "lp_simplex_row: bad row or null output");
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    LP_HIP(ctx, hipMemcpyAsync(out, p->dev.T + (size_t)row * p->dev.ld, sizeof(double) * (size_t)(p->dev.n + 1),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LP_OPTIMAL;
+}
+
+int lp_simplex_force_pivot(lp_simplex_problem* p, int row, int col) {
+    if (!p) return LP_BAD_ARG;
+    lp_context* ctx = p->ctx;
+    if (row < 0 || row >= p->dev.m || col < 0 || col >= p->dev.n)
+        LP_FAIL(ctx, LP_BAD_ARG, "lp_simplex_force_pivot: position outside the tableau");
+    if (p->init_status != LP_OPTIMAL) LP_FAIL(ctx, LP_SINGULAR, "lp_simplex_force_pivot: the initial basis was singular");
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    return lp_simplex_force(p, row, col);
+}
+
+// Two-phase simplex: the host logic of the flow, every pivot on the GPU.
+int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const double* b,
+                         const double* c, int maximize, int n_orig, double eps, int max_iter,
+                         double* x_out, int* basis_out, double* obj_out, int* iters_out) {
+    if (!ctx) return LP_BAD_ARG;
+    if (!A || !b || !c || !x_out) LP_FAIL(ctx, LP_BAD_ARG, "lp_simplex_two_phase: null argument");
+    if (m <= 0 || n < m || n_orig <= 0 || n_orig > n) LP_FAIL(ctx, LP_BAD_ARG, "lp_simplex_two_phase: bad dimensions");
+    const int na = n + m;
+    std::vector<double> A1((size_t)m * na, 0.0), b1((size_t)m), c1((size_t)na, 0.0), xa((size_t)na);
+    std::vector<int> N((size_t)m);
+    int it[3] = {0, 0, 0};
+    if (iters_out) std::memcpy(iters_out, it, sizeof(it));
+    // make_b_nonneg (:61-68) and createAuxiliaryProblem (:70-95)
+    for (int i = 0; i < m; ++i) {
+        const bool flip = b[i] < -eps;
+        b1[i] = flip ? -b[i] : b[i];
+        for (int j = 0; j < n; ++j) A1[(size_t)j * m + i] = flip ? -A[(size_t)j * m + i] : A[(size_t)j * m + i];
+        A1[(size_t)(n + i) * m + i] = 1.0;
+    }
+    for (int j = n; j < na; ++j) c1[j] = 1.0;
+    for (int t = 0; t < m; ++t) N[t] = n + t;
+    // ---- phase I: minimise the sum of the artificials
+    lp_simplex_problem* p = nullptr;
+    int rc = lp_simplex_upload(ctx, A1.data(), m, na, b1.data(), c1.data(), N.data(), 0, na, &p);
+    if (rc) return rc;
+    lp_simplex_stats st;
+    rc = lp_simplex_run(p, eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
+    it[0] = st.pivots;
+    if (rc == LP_OPTIMAL) rc = lp_simplex_download(p, xa.data(), N.data(), nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc == LP_OPTIMAL) {
+        double sum = 0.0;  // :347-350
+        for (int i = 0; i < m; ++i) sum += xa[(size_t)n + i];
+        if (sum > eps) {  // :352-353
+            rc = LP_INFEASIBLE;
+            ctx->last_error = "two-phase: the problem has no feasible solution (phase I optimum > eps)";
+        }
+    }
+    if (rc == LP_OPTIMAL) {
+        // replaceArtificialColumns (:331-381)
+        std::vector<double> trow((size_t)na + 1);
+        std::vector<unsigned char> basic((size_t)na);
+        for (int pos = 0; pos < m && rc == LP_OPTIMAL; ++pos) {
+            if (N[pos] < n) continue;
+            rc = lp_simplex_row(p, pos, trow.data());
+            if (rc) break;
+            std::fill(basic.begin(), basic.end(), (unsigned char)0);
+            for (int t = 0; t < m; ++t) basic[(size_t)N[t]] = 1;
+            int cand = -1;
+            for (int j = 0; j < n; ++j)
+                if (!basic[j] && std::fabs(trow[j]) > eps) {
+                    cand = j;
+                    break;
+                }
+            if (cand < 0) {
+                rc = LP_SINGULAR;  // :372-380: linearly dependent constraints
+                ctx->last_error = "two-phase: an artificial variable cannot leave the basis (linearly dependent constraints)";
+                break;
+            }
+            rc = lp_simplex_force_pivot(p, pos, cand);
+            N[pos] = cand;
+            ++it[1];
+        }
+    }
+    lp_simplex_free(p);
+    // ---- phase II from the clean basis (:383-404)
+    if (rc == LP_OPTIMAL)
+        rc = lp_simplex_solve(ctx, A1.data(), m, n, b1.data(), c, N.data(), maximize, n_orig, eps, max_iter, x_out,
+                              N.data(), obj_out, &it[2]);
+    if (basis_out) std::memcpy(basis_out, N.data(), sizeof(int) * (size_t)m);
+    if (iters_out) std::memcpy(iters_out, it, sizeof(it));
+    return rc;
+}
+
 // Diagnostic: switches the look-ahead selector's per-phase cycle stamps on (cap_pivots > 0)
 // and, after a run, copies them out: 8 stamps per pivot (s_memtime ticks).
 int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long long* out) {
@@ -393,7 +487,7 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6); (void)hipFree(p->dcomb7);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
     (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.item_count);
     if (p->h_item_count) (void)hipHostFree(p->h_item_count);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
@@ -498,26 +592,8 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         }
         LP_TRY(hipMalloc(&p->dcomb6, sizeof(unsigned) * comb6.size()));
         LP_TRY(hipMemcpyAsync(p->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
-        // thin leaf kernel: 7-subsets of 7, 8 and 9 columns, 4 bits per index
-        std::vector<unsigned> comb7(3 * 36, 0u);
-        for (int R9 = 7; R9 <= 9; ++R9) {
-            int s7[7] = {0, 1, 2, 3, 4, 5, 6};
-            for (int k = 0;; ++k) {
-                unsigned pk = 0;
-                for (int t = 0; t < 7; ++t) pk |= (unsigned)s7[t] << (4 * t);
-                comb7[(size_t)36 * (R9 - 7) + k] = pk;
-                int t = 6;
-                while (t >= 0 && s7[t] == R9 - 7 + t) --t;
-                if (t < 0) break;
-                ++s7[t];
-                for (int u = t + 1; u < 7; ++u) s7[u] = s7[u - 1] + 1;
-            }
-        }
-        LP_TRY(hipMalloc(&p->dcomb7, sizeof(unsigned) * comb7.size()));
-        LP_TRY(hipMemcpyAsync(p->dcomb7, comb7.data(), sizeof(unsigned) * comb7.size(), hipMemcpyHostToDevice, s));
-        LP_TRY(hipStreamSynchronize(s));  // comb6 / comb7 are locals
+        LP_TRY(hipStreamSynchronize(s));  // comb6 is a local
         pd.comb6 = p->dcomb6;
-        pd.comb7 = p->dcomb7;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

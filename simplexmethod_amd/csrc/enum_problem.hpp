@@ -62,7 +62,6 @@ struct PrefixDev {
     int4* items;                      // leaf-kernel work items: (record, child column, chunk, rank offset)
     int* item_count;
     int item_cap;
-    const unsigned* comb7;            // [3][36]: 7-subsets of 7, 8, 9 columns in lex order, 4 bits per index
     const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
                                       // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]
     unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
@@ -92,7 +91,6 @@ struct lp_enum_problem {
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
     unsigned* dcomb6 = nullptr;
-    unsigned* dcomb7 = nullptr;
     int* h_item_count = nullptr;               // pinned
     int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned

@@ -263,6 +263,28 @@ __global__ __launch_bounds__(1024) void k_crash_select(SimplexDev d, int t) {
     for (int j = tid; j < ld; j += blockDim.x) d.prow[j] = trow[j];
 }
 
+// A pivot the HOST chose (two-phase drive-out, SimplexSolover.h:331-381 replaceArtificialColumns):
+// stage the eta column and the pivot-row copy for (row, col) of the current tableau with the
+// selectors' arithmetic, update the basis bookkeeping; k_simplex_update then applies it.
+__global__ __launch_bounds__(1024) void k_force_select(SimplexDev d, int row, int col) {
+    SimplexState* st = d.state;
+    const int tid = threadIdx.x, m = d.m, ld = d.ld;
+    const double ur = d.T[(size_t)row * ld + col];
+    for (int i = tid; i <= m; i += blockDim.x)
+        d.lcol[i] = (i == row) ? 1.0 / ur : -d.T[(size_t)i * ld + col] / ur;
+    const double* trow = d.T + (size_t)row * ld;
+    for (int j = tid; j < ld; j += blockDim.x) d.prow[j] = trow[j];
+    if (tid == 0) {
+        const int old = d.basis[row];
+        d.basis[row] = col;
+        d.nonbasic[col] = 0;
+        d.nonbasic[old] = 1;
+        st->enter = col;
+        st->leave = row;
+        st->pivot_valid = 1;
+    }
+}
+
 // Singularity verdict after the m crash pivots (min|piv| <= eps_mach*m*max|piv|, the
 // FullPivLU::isInvertible threshold the reference relies on at :124-126) and the
 // row permutation to basis-position order: dst row t = src row rowpos[t].
@@ -313,6 +335,15 @@ __global__ void k_scatter_x(SimplexDev d, double* x) {
 
 static dim3 update_grid(const SimplexDev& d) {
     return dim3(lp_ceil_div(d.ld / 2, UPD_TX), lp_ceil_div(d.m + 1, UPD_TY * UPD_RPT));
+}
+
+int lp_simplex_force(lp_simplex_problem* p, int row, int col) {
+    lp_context* ctx = p->ctx;
+    hipLaunchKernelGGL(k_force_select, 1, 1024, 0, ctx->stream, p->dev, row, col);
+    lp_simplex_launch_update(p);
+    LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LP_HIP(ctx, hipGetLastError());
+    return LP_OPTIMAL;
 }
 
 void lp_simplex_launch_update(lp_simplex_problem* p) {

@@ -75,6 +75,33 @@ TEST(Solvers_CrossCheck_Random) {   // README.md:42
         CHECK(std::fabs(can->Evaluate([&] { VectorXd f = VectorXd::Zero(m + no); for (int j = 0; j < no; ++j) f[j] = s.x[j]; return f; }()) - s.objective) < 1e-9);
     }
 }
+TEST(Solver_TwoPhase) {   // SURVEY 8(f) N2; flow of SimplexSolover.h:61-95,331-406 designed afresh
+    // min 2x1+3x2, x1+x2 >= 4, x1+3x2 >= 6 in canonical form [A | -I]; the basis indices given to
+    // Canonical are placeholders (its constructor wants m of them), twoPhaseSimplex ignores them
+    Canonical can(mat(2, 4, {1, 1, -1, 0, 1, 3, 0, -1}), vec({4, 6}), vec({2, 3, 0, 0}), {0, 1}, true);
+    can.SetOriginalVariablesCount(2);
+    Solver s(can);
+    VectorXd x = s.twoPhaseSimplex();
+    CHECK(x.size() == 2 && x[0] == 3 && x[1] == 1);
+    int it[3];
+    auto r = s.twoPhaseSimplex_ex(true, it);
+    CHECK(r.objective == 9 && it[0] == 2 && it[1] == 0 && r.status == LP_OPTIMAL);
+    // the enumeration solver agrees (README.md:42)
+    auto e = EnumerationSolver(can).solve_ex();
+    CHECK(e.objective == 9 && e.x[0] == 3 && e.x[1] == 1);
+    // no feasible point: x1+x2+s = 1, x1+x2-t = 3  (:352-353)
+    Canonical nofeas(mat(2, 4, {1, 1, 1, 0, 1, 1, 0, -1}), vec({1, 3}), vec({1, 1, 0, 0}), {0, 1}, true);
+    CHECK_THROWS(Solver(nofeas).twoPhaseSimplex(), std::runtime_error);
+    CHECK(Solver(nofeas).twoPhaseSimplex_ex(false).status == LP_INFEASIBLE);
+    // linearly dependent constraints (:372-380)
+    Canonical dep(mat(2, 2, {1, 1, 1, 1}), vec({2, 2}), vec({1, 2}), {0, 1}, true);
+    CHECK(Solver(dep).twoPhaseSimplex_ex(false).status == LP_SINGULAR);
+    // negative right-hand side (make_b_nonneg, :61-68): -x1-x2+s = -2, min x1+2x2 -> (2, 0)
+    Canonical neg(mat(1, 3, {-1, -1, 1}), vec({-2}), vec({1, 2, 0}), {0}, true);
+    neg.SetOriginalVariablesCount(2);
+    VectorXd xn = Solver(neg).twoPhaseSimplex();
+    CHECK(xn[0] == 2 && xn[1] == 0);
+}
 TEST(Enumeration_MultiGpuShardsOnOneDevice) {
     // n_gpus = 1 path vs the sharded host-thread path cannot be exercised with >1 device here;
     // a single device run must at least agree with itself across repeated solves.

@@ -53,4 +53,23 @@ for k in range(10):
     st, xB, z = o.enum_subset(A, b, c, o.unrank(5, 2, k))
     table.append(dict(rank=k, subset=o.unrank(5, 2, k).tolist(), verdict=st, xB=xB.tolist(), z=z))
 json.dump(dict(random=enum, input_symmetric=table), open(os.path.join(HERE, "enum_cases.json"), "w"), indent=1)
-print("wrote", len(simplex), "simplex cases and", len(enum), "enumeration cases")
+
+# two-phase simplex: min problems without a starting basis, optimum cross-checked
+# against scipy's HiGHS; inputs are regenerated from seeds by tests/lpcases.py
+from tests import lpcases                 # noqa: E402
+two = []
+for kind, seed, args in [("min", 0, (5, 4, 0, 0, 0)), ("min", 1, (6, 5, 1, 2, 0)), ("min", 3, (16, 12, 3, 4, 2)),
+                         ("min", 5, (64, 64, 4, 8, 3)), ("deg", 7, ()), ("deg", 34, ()), ("deg", 40, ())]:
+    if kind == "min":
+        A, b, c, no = lpcases.min_lp(seed, args[0], args[1], equalities=args[2], negative_rows=args[3],
+                                     zero_rhs=args[4])
+    else:
+        A, b, c, no = lpcases.degenerate_eq_lp(seed)
+    r = o.two_phase(A, b, c, maximize=False, n_orig=no)
+    assert r["status"] == 0
+    ref = linprog(c, A_eq=A, b_eq=b, bounds=(0, None), method="highs")
+    assert ref.status == 0 and abs(r["obj"] - ref.fun) <= 1e-9 * max(1.0, abs(ref.fun)), (kind, seed)
+    two.append(dict(kind=kind, seed=seed, args=list(args), iters=r["iters"], basis=r["basis"].tolist(),
+                    obj=r["obj"], x=r["x"].tolist()))
+json.dump(two, open(os.path.join(HERE, "two_phase_cases.json"), "w"), indent=1)
+print("wrote", len(simplex), "simplex cases,", len(enum), "enumeration cases and", len(two), "two-phase cases")

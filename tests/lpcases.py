@@ -50,3 +50,46 @@ def general_lp(seed, m, n, signed=True):
     c2 = np.concatenate([c, [0.0]])
     basis2 = np.concatenate([basis, [n]]).astype(np.int32)
     return A2, b2, c2, basis2
+
+
+def min_lp(seed, m, k, equalities=0, negative_rows=0, zero_rhs=0):
+    """Random Symmetrical-style MIN problem in canonical form WITHOUT a starting basis
+    (SURVEY 8(f) N2): min c.x, A0 x >= b  ->  [A0 | -I], surplus columns, n = k + m.
+    equalities: the first rows get no surplus column weight (their -1 is zeroed: an equality
+    row); negative_rows: that many rows are multiplied by -1 (b < 0: exercises make_b_nonneg);
+    zero_rhs: that many rows get b = 0 (degenerate: artificials may stay basic at level 0)."""
+    rng = np.random.default_rng(1000 + seed)
+    A0 = rng.uniform(0.0, 1.0, size=(m, k))
+    b = rng.uniform(1.0, 2.0, size=m)
+    c = np.concatenate([rng.uniform(0.1, 1.0, size=k), np.zeros(m)])
+    S = -np.eye(m)
+    for i in range(equalities):
+        S[i, i] = 0.0
+    if equalities:  # keep the problem feasible: equality rows hold at a positive point
+        x0 = rng.uniform(0.5, 1.5, size=k)
+        b[:equalities] = A0[:equalities] @ x0
+        b[equalities:] = np.minimum(b[equalities:], A0[equalities:] @ x0)
+    for i in range(zero_rhs):
+        b[m - 1 - i] = 0.0
+    A = np.hstack([A0, S])
+    for i in range(negative_rows):
+        A[i] = -A[i]
+        b[i] = -b[i]
+    return A, b, c, k
+
+
+def degenerate_eq_lp(seed, m=4, k=7, zero_rows=2):
+    """Equality-form min problem A x = b, x >= 0 with `zero_rows` rows of rhs exactly 0 that the
+    feasible point x0 satisfies: phase I of the two-phase simplex often ends with an artificial
+    still basic at level 0, which exercises replaceArtificialColumns (SimplexSolover.h:331-381)."""
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(-1, 1, (m, k))
+    x0 = np.concatenate([rng.uniform(0.5, 1.5, 3), np.zeros(k - 3)])
+    b = A @ x0
+    for i in range(m - zero_rows, m):
+        a = rng.uniform(-1, 1, k)
+        a[:3] -= (a[:3] @ x0[:3]) / (x0[:3] @ x0[:3]) * x0[:3]
+        A[i] = a
+        b[i] = 0.0
+    c = rng.uniform(0.1, 1, k)
+    return A, b, c, k
