@@ -168,6 +168,27 @@ def batched_leg(ctx, args):
     }
 
 
+def two_phase_leg(ctx, args):
+    """a Symmetrical-style MIN problem (no starting basis) through
+    lp_simplex_two_phase; host-buffer entry point, so the time includes both uploads."""
+    m = k = 256
+    rng = np.random.default_rng(0)
+    A = np.hstack([rng.uniform(0.0, 1.0, size=(m, k)), -np.eye(m)])
+    b = rng.uniform(1.0, 2.0, size=m)
+    c = np.concatenate([rng.uniform(0.1, 1.0, size=k), np.zeros(m)])
+    ctx.two_phase(A, b, c, maximize=False, n_orig=k)  # warm-up
+    best, r = 1e9, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = ctx.two_phase(A, b, c, maximize=False, n_orig=k)
+        best = min(best, time.perf_counter() - t0)
+    return {
+        "workload": f"min c.x, A0 x >= b, A0 {m}x{k} U(0,1) seed 0: canonical [A0|-I] {m}x{m + k}, no starting basis",
+        "status": int(r["status"]), "pivots_phase1_driveout_phase2": r["iters"],
+        "crash_pivots": 2 * m, "ms_host_inclusive": round(best * 1e3, 3), "objective": r["obj"],
+    }
+
+
 def cpu_baseline_leg(args):
     """Oracle (restatement of the reference CPU path) on this host, 1 thread, bounded sample."""
     from oracle import pyoracle as o
@@ -308,6 +329,7 @@ def main():
         line["roofline"] = roofline
     if rank == 0 and not args.no_batched:
         line["batched"] = batched_leg(ctx, args)
+        line["two_phase"] = two_phase_leg(ctx, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_leg(args)
     ep.free()

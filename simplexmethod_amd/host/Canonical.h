@@ -1,6 +1,5 @@
 // Canonical.h — canonical form  opt c.x, Ax = b, x >= 0  with a starting basis.
-// Same public surface as /root/reference/src/ProblemTypes/Canonical.h:10-49 minus the
-// conversions SURVEY.md §8 marks out of scope (ToCommon / ToSymmetrical / GetDual: N4).
+// Same public surface as /root/reference/src/ProblemTypes/Canonical.h:10-49.
 #pragma once
 
 #include <memory>
@@ -9,6 +8,7 @@
 #include "IProblem.h"
 
 class Symmetrical;
+class Common;
 
 class Canonical : public IProblem {
 public:
@@ -29,6 +29,13 @@ public:
     void SetOriginalVariablesCount(int count);                         // Canonical.cpp:156-163
     bool IsFeasibleBasis() const;                                      // Canonical.cpp:165-177
     lpla::VectorXd GetBasicSolution() const;                           // Canonical.cpp:179-197
+
+    // conversions over the ORIGINAL variables only (slack / surplus / artificial columns dropped)
+    std::unique_ptr<Common> ToCommon() const;             // all rows '=', all x >= 0 (:199-229)
+    std::unique_ptr<Symmetrical> ToSymmetrical() const;   // each row -> the pair (a, b), (-a, -b) (:231-300)
+    // dual of  opt c.x, Ax = b, x >= 0  in canonical form: [A^T | -A^T | I], costs [b | -b | 0],
+    // rhs c, slack basis, opposite sense (:303-364)
+    std::unique_ptr<Canonical> GetDual() const;
 
 private:
     lpla::MatrixXd A_;

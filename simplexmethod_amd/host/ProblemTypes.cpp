@@ -4,6 +4,7 @@
 #include <stdexcept>
 
 #include "Canonical.h"
+#include "Common.h"
 #include "Symmetrical.h"
 
 using lpla::MatrixXd;
@@ -185,4 +186,166 @@ void Symmetrical::Print() const {
     std::cout << "  c:";
     for (long j = 0; j < c_.size(); ++j) std::cout << " " << c_[j];
     std::cout << "\n";
+}
+
+// ---------------------------------------------------------------------------
+// Conversions of SURVEY.md §8(f) N4 (CPU modelling glue, O(mn))
+// ---------------------------------------------------------------------------
+
+std::unique_ptr<Common> Symmetrical::ToCommon() const {
+    const auto row = maximize_ ? Common::ConstraintType::LessOrEqual : Common::ConstraintType::GreaterOrEqual;
+    return std::make_unique<Common>(A_, b_, c_, std::vector<Common::ConstraintType>((size_t)A_.rows(), row),
+                                    std::vector<Common::VariableType>((size_t)A_.cols(), Common::VariableType::NonNegative),
+                                    maximize_);
+}
+
+namespace {
+// the first n_keep columns of A and entries of c
+void original_part(const MatrixXd& A, const VectorXd& c, long n_keep, MatrixXd& Ao, VectorXd& co) {
+    Ao = MatrixXd(A.rows(), n_keep);
+    co = VectorXd(n_keep);
+    for (long j = 0; j < n_keep; ++j) {
+        co[j] = c[j];
+        for (long i = 0; i < A.rows(); ++i) Ao(i, j) = A(i, j);
+    }
+}
+}  // namespace
+
+std::unique_ptr<Common> Canonical::ToCommon() const {
+    MatrixXd Ao;
+    VectorXd co;
+    original_part(A_, c_, originalVariablesCount_, Ao, co);
+    return std::make_unique<Common>(Ao, b_, co,
+                                    std::vector<Common::ConstraintType>((size_t)A_.rows(), Common::ConstraintType::Equal),
+                                    std::vector<Common::VariableType>((size_t)originalVariablesCount_, Common::VariableType::NonNegative),
+                                    !minimize_);
+}
+
+std::unique_ptr<Symmetrical> Canonical::ToSymmetrical() const {
+    MatrixXd Ao;
+    VectorXd co;
+    original_part(A_, c_, originalVariablesCount_, Ao, co);
+    const long m = A_.rows(), n = originalVariablesCount_;
+    // a.x = b  ->  a.x (<=|>=) b  and  -a.x (<=|>=) -b : the same pair of rows for either sense
+    MatrixXd As(2 * m, n);
+    VectorXd bs(2 * m);
+    for (long i = 0; i < m; ++i) {
+        for (long j = 0; j < n; ++j) {
+            As(2 * i, j) = Ao(i, j);
+            As(2 * i + 1, j) = -Ao(i, j);
+        }
+        bs[2 * i] = b_[i];
+        bs[2 * i + 1] = -b_[i];
+    }
+    return std::make_unique<Symmetrical>(As, bs, co, !minimize_);
+}
+
+std::unique_ptr<Canonical> Canonical::GetDual() const {
+    const long m = A_.rows(), n = A_.cols();
+    MatrixXd Ad(n, 2 * m + n);
+    VectorXd cd = VectorXd::Zero(2 * m + n);
+    for (long i = 0; i < m; ++i) {
+        cd[i] = b_[i];          // y'
+        cd[m + i] = -b_[i];     // y''   (free y = y' - y'')
+        for (long j = 0; j < n; ++j) {
+            Ad(j, i) = A_(i, j);
+            Ad(j, m + i) = -A_(i, j);
+        }
+    }
+    std::vector<int> basis((size_t)n);
+    for (long j = 0; j < n; ++j) {
+        Ad(j, 2 * m + j) = 1.0;  // slack of A^T y <= c
+        basis[(size_t)j] = (int)(2 * m + j);
+    }
+    auto dual = std::make_unique<Canonical>(Ad, c_, cd, basis, !minimize_);
+    dual->SetOriginalVariablesCount((int)(2 * m));
+    return dual;
+}
+
+// ---- Common ---------------------------------------------------------------
+
+Common::Common(const MatrixXd& A, const VectorXd& b, const VectorXd& c,
+               const std::vector<ConstraintType>& constraintTypes,
+               const std::vector<VariableType>& variableTypes, bool maximize)
+    : A_(A), b_(b), c_(c), ctypes_(constraintTypes), vtypes_(variableTypes), maximize_(maximize) {
+    if (A_.rows() != b_.size()) throw std::invalid_argument("Common: rows(A) != size(b)");
+    if (A_.cols() != c_.size()) throw std::invalid_argument("Common: cols(A) != size(c)");
+    if ((long)ctypes_.size() != A_.rows()) throw std::invalid_argument("Common: one constraint type per row of A expected");
+    if ((long)vtypes_.size() != A_.cols()) throw std::invalid_argument("Common: one variable type per column of A expected");
+}
+
+double Common::Evaluate(const VectorXd& solution) const {
+    if (solution.size() != c_.size()) throw std::invalid_argument("Common::Evaluate: solution size != variable count");
+    return c_.dot(solution);
+}
+
+void Common::Print() const {
+    std::cout << "general form: " << (maximize_ ? "maximize" : "minimize");
+    for (long j = 0; j < c_.size(); ++j) std::cout << (j ? " + " : " ") << c_[j] << "*x" << (j + 1);
+    std::cout << "\n";
+    for (long i = 0; i < A_.rows(); ++i) {
+        for (long j = 0; j < A_.cols(); ++j) std::cout << (j ? " + " : "  ") << A_(i, j) << "*x" << (j + 1);
+        const char* rel = ctypes_[(size_t)i] == ConstraintType::LessOrEqual ? " <= "
+                          : ctypes_[(size_t)i] == ConstraintType::GreaterOrEqual ? " >= " : " = ";
+        std::cout << rel << b_[i] << "\n";
+    }
+    for (size_t j = 0; j < vtypes_.size(); ++j)
+        std::cout << "  x" << (j + 1)
+                  << (vtypes_[j] == VariableType::Free ? " free" : vtypes_[j] == VariableType::NonNegative ? " >= 0" : " <= 0")
+                  << "\n";
+}
+
+std::unique_ptr<Symmetrical> Common::ToSymmetrical() const {
+    // Every output column is (source column, sign) and every output row is (source row, sign):
+    // A_sym(r, k) = sign_r * sign_k * A(i, j).  Signs: x_j <= 0 enters as -x'; free x_j as the pair
+    // (+x', -x''); a >= row is negated; an = row becomes the pair (+, -).  The result is always the
+    // max / <= form, so a min objective is negated (Common.cpp:169-388).
+    struct Part { long src; double sign; };
+    std::vector<Part> cols, rows;
+    for (long j = 0; j < A_.cols(); ++j) {
+        switch (vtypes_[(size_t)j]) {
+            case VariableType::NonNegative: cols.push_back({j, 1.0}); break;
+            case VariableType::NonPositive: cols.push_back({j, -1.0}); break;
+            case VariableType::Free: cols.push_back({j, 1.0}); cols.push_back({j, -1.0}); break;
+        }
+    }
+    for (long i = 0; i < A_.rows(); ++i) {
+        switch (ctypes_[(size_t)i]) {
+            case ConstraintType::LessOrEqual: rows.push_back({i, 1.0}); break;
+            case ConstraintType::GreaterOrEqual: rows.push_back({i, -1.0}); break;
+            case ConstraintType::Equal: rows.push_back({i, 1.0}); rows.push_back({i, -1.0}); break;
+        }
+    }
+    MatrixXd As((long)rows.size(), (long)cols.size());
+    VectorXd bs((long)rows.size()), cs((long)cols.size());
+    const double csign = maximize_ ? 1.0 : -1.0;
+    for (size_t k = 0; k < cols.size(); ++k) {
+        cs[(long)k] = csign * (cols[k].sign * c_[cols[k].src]);
+        for (size_t r = 0; r < rows.size(); ++r)
+            As((long)r, (long)k) = rows[r].sign * (cols[k].sign * A_(rows[r].src, cols[k].src));
+    }
+    for (size_t r = 0; r < rows.size(); ++r) bs[(long)r] = rows[r].sign * b_[rows[r].src];
+    return std::make_unique<Symmetrical>(As, bs, cs, true);
+}
+
+std::unique_ptr<Canonical> Common::ToCanonical() const { return ToSymmetrical()->ToCanonical(); }
+
+std::unique_ptr<Common> Common::GetDual() const {
+    // max problem: row <= -> y >= 0, row >= -> y <= 0, row = -> y free; x >= 0 -> dual row >=,
+    // x <= 0 -> dual row <=, x free -> dual row =.  A min problem mirrors every inequality.
+    std::vector<VariableType> vt((size_t)A_.rows());
+    std::vector<ConstraintType> ct((size_t)A_.cols());
+    for (size_t i = 0; i < vt.size(); ++i) {
+        const ConstraintType t = ctypes_[i];
+        vt[i] = t == ConstraintType::Equal ? VariableType::Free
+                : ((t == ConstraintType::LessOrEqual) == maximize_) ? VariableType::NonNegative
+                                                                    : VariableType::NonPositive;
+    }
+    for (size_t j = 0; j < ct.size(); ++j) {
+        const VariableType t = vtypes_[j];
+        ct[j] = t == VariableType::Free ? ConstraintType::Equal
+                : ((t == VariableType::NonNegative) == maximize_) ? ConstraintType::GreaterOrEqual
+                                                                  : ConstraintType::LessOrEqual;
+    }
+    return std::make_unique<Common>(A_.transpose(), c_, b_, ct, vt, !maximize_);
 }

@@ -1,6 +1,5 @@
 // Symmetrical.h — symmetric form  max c.x, Ax <= b  (or min, Ax >= b),  x >= 0.
-// Same public surface as /root/reference/src/ProblemTypes/Symmetrical.h:16-45 minus ToCommon
-// (N4).
+// Same public surface as /root/reference/src/ProblemTypes/Symmetrical.h:16-45.
 #pragma once
 
 #include <memory>
@@ -8,6 +7,7 @@
 #include "IProblem.h"
 
 class Canonical;
+class Common;
 
 class Symmetrical : public IProblem {
 public:
@@ -26,6 +26,8 @@ public:
     // max: [A | I], slack basis, zero slack costs, Canonical(minimize=false);
     // min: [A | -I | I], artificial basis with zero cost (Symmetrical.cpp:142-223).
     std::unique_ptr<Canonical> ToCanonical() const;
+    // same data, every row <= (max) or >= (min), every variable >= 0 (Symmetrical.cpp:225-273)
+    std::unique_ptr<Common> ToCommon() const;
 
 private:
     lpla::MatrixXd A_;

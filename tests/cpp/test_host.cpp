@@ -1,8 +1,9 @@
 // CPU-only tests of the host problem classes; the cases and expected values are the
 // reference's own (tests/test_canonical.cpp, test_symmetrical.cpp, test_parser.cpp,
-// test_transformations.cpp:39-61, test_common.cpp:49-59) restated without gtest/Eigen.
+// test_transformations.cpp, test_common.cpp) restated without gtest/Eigen.
 #include "check.h"
 #include "Canonical.h"
+#include "Common.h"
 #include "Symmetrical.h"
 #include "SymmetricalParser.h"
 
@@ -148,6 +149,117 @@ TEST(Parser_InputSymmetricFixture) {
     CHECK(s->GetObjectiveCoefficients()[0] == 7 && s->GetRightHandSide()[1] == 20 && s->GetConstraintsMatrix()(1, 2) == 6);
     auto c = s->ToCanonical();
     CHECK(c->GetConstraintsMatrix().cols() == 5 && c->GetBasisIndices()[0] == 3 && c->GetBasisIndices()[1] == 4);
+}
+
+// ---- test_common.cpp (fixture :10-29: A = [1 2; 3 4], b = (5,6), c = (7,8), rows (<=, >=), x >= 0)
+using CT = Common::ConstraintType;
+using VT = Common::VariableType;
+static Common fixture_common(bool maximize = true) {
+    return Common(SA(), vec({5, 6}), vec({7, 8}), {CT::LessOrEqual, CT::GreaterOrEqual},
+                  {VT::NonNegative, VT::NonNegative}, maximize);
+}
+TEST(Common_Creation) {                          // :38-47
+    Common c = fixture_common();
+    CHECK(c.IsMaximization());
+    CHECK(c.GetConstraintsMatrix().rows() == 2 && c.GetConstraintsMatrix().cols() == 2);
+    CHECK(c.GetRightHandSide().size() == 2 && c.GetObjectiveCoefficients().size() == 2);
+}
+TEST(Common_Evaluate) {                          // :49-59: 7*1 + 8*2 = 23
+    CHECK(fixture_common().Evaluate(vec({1, 2})) == 23.0);
+    CHECK_THROWS(fixture_common().Evaluate(vec({1, 2, 3})), std::invalid_argument);
+}
+TEST(Common_InvalidDimensions) {                 // :61-70 + Common.cpp:28-43
+    CHECK_THROWS(Common(SA(), vec({1, 2, 3}), vec({7, 8}), {CT::LessOrEqual, CT::GreaterOrEqual},
+                        {VT::NonNegative, VT::NonNegative}, true), std::invalid_argument);
+    CHECK_THROWS(Common(SA(), vec({5, 6}), vec({7, 8, 9}), {CT::LessOrEqual, CT::GreaterOrEqual},
+                        {VT::NonNegative, VT::NonNegative}, true), std::invalid_argument);
+    CHECK_THROWS(Common(SA(), vec({5, 6}), vec({7, 8}), {CT::LessOrEqual}, {VT::NonNegative, VT::NonNegative}, true),
+                 std::invalid_argument);
+    CHECK_THROWS(Common(SA(), vec({5, 6}), vec({7, 8}), {CT::LessOrEqual, CT::Equal}, {VT::Free}, true),
+                 std::invalid_argument);
+}
+TEST(Common_Copy) {                              // :72-79
+    Common a = fixture_common();
+    Common b2(a);
+    CHECK(b2.IsMaximization() && b2.GetConstraintsMatrix().rows() == 2);
+    Common c3 = fixture_common(false);
+    c3 = a;
+    CHECK(c3.IsMaximization());
+}
+TEST(Common_GetDual) {                           // :81-94 + the rules of Common.cpp:403-448
+    auto d = fixture_common().GetDual();
+    CHECK(d && !d->IsMaximization());
+    CHECK(d->GetConstraintsMatrix().rows() == 2 && d->GetConstraintsMatrix().cols() == 2);
+    CHECK(d->GetConstraintsMatrix()(0, 1) == 3 && d->GetConstraintsMatrix()(1, 0) == 2);   // A^T
+    CHECK(d->GetRightHandSide()[0] == 7 && d->GetObjectiveCoefficients()[1] == 6);         // b <-> c
+    // max: row <= -> y >= 0, row >= -> y <= 0; x >= 0 -> dual row >=
+    CHECK(d->GetVariableTypes()[0] == VT::NonNegative && d->GetVariableTypes()[1] == VT::NonPositive);
+    CHECK(d->GetConstraintTypes()[0] == CT::GreaterOrEqual && d->GetConstraintTypes()[1] == CT::GreaterOrEqual);
+    // min mirrors every inequality; '=' <-> free
+    Common m(SA(), vec({5, 6}), vec({7, 8}), {CT::Equal, CT::GreaterOrEqual}, {VT::Free, VT::NonPositive}, false);
+    auto dm = m.GetDual();
+    CHECK(dm->IsMaximization());
+    CHECK(dm->GetVariableTypes()[0] == VT::Free && dm->GetVariableTypes()[1] == VT::NonNegative);
+    CHECK(dm->GetConstraintTypes()[0] == CT::Equal && dm->GetConstraintTypes()[1] == CT::GreaterOrEqual);
+    // the dual of the dual is the problem itself
+    auto dd = dm->GetDual();
+    CHECK(!dd->IsMaximization() && dd->GetConstraintTypes()[0] == CT::Equal && dd->GetConstraintTypes()[1] == CT::GreaterOrEqual);
+    CHECK(dd->GetVariableTypes()[0] == VT::Free && dd->GetVariableTypes()[1] == VT::NonPositive);
+    CHECK(dd->GetConstraintsMatrix() == SA());
+}
+// ---- test_transformations.cpp:5-37 and the conversion rules of Common.cpp:169-388
+TEST(Common_ToSymmetricalToCanonical) {
+    Common c(SA(), vec({5, 6}), vec({7, 8}), {CT::LessOrEqual, CT::LessOrEqual}, {VT::NonNegative, VT::NonNegative}, true);
+    auto s = c.ToSymmetrical();
+    CHECK(s && s->IsMaximization() && s->GetConstraintsMatrix() == SA());
+    auto can = s->ToCanonical();
+    CHECK(can && can->GetConstraintsMatrix().rows() == 2);
+    CHECK(c.ToCanonical()->GetConstraintsMatrix() == can->GetConstraintsMatrix());
+}
+TEST(Common_ToSymmetricalRules) {
+    // min 7x1 + 8x2 + 9x3;  x1 + 2x2 + 3x3 <= 5,  4x1 + 5x2 + 6x3 >= 6,  x1 - x2 = 1;
+    // x1 >= 0, x2 <= 0, x3 free
+    Common c(mat(3, 3, {1, 2, 3, 4, 5, 6, 1, -1, 0}), vec({5, 6, 1}), vec({7, 8, 9}),
+             {CT::LessOrEqual, CT::GreaterOrEqual, CT::Equal}, {VT::NonNegative, VT::NonPositive, VT::Free}, false);
+    auto s = c.ToSymmetrical();
+    CHECK(s->IsMaximization());   // always the max / <= form
+    // columns: x1, -x2', x3', -x3'';  rows: row0, -row1, row2, -row2
+    const MatrixXd expect = mat(4, 4, {1, -2, 3, -3,
+                                       -4, 5, -6, 6,
+                                       1, 1, 0, -0.0,
+                                       -1, -1, -0.0, 0});
+    CHECK(s->GetConstraintsMatrix() == expect);
+    CHECK(s->GetRightHandSide() == vec({5, -6, 1, -1}));
+    CHECK(s->GetObjectiveCoefficients() == vec({-7, 8, -9, 9}));   // min -> max: negated
+}
+TEST(Symmetrical_ToCommon) {                     // Symmetrical.cpp:225-273
+    auto c = Symmetrical(SA(), vec({5, 6}), vec({7, 8}), true).ToCommon();
+    CHECK(c->IsMaximization() && c->GetConstraintsMatrix() == SA());
+    CHECK(c->GetConstraintTypes()[0] == CT::LessOrEqual && c->GetConstraintTypes()[1] == CT::LessOrEqual);
+    CHECK(c->GetVariableTypes()[0] == VT::NonNegative && c->GetVariableTypes()[1] == VT::NonNegative);
+    auto m = Symmetrical(SA(), vec({5, 6}), vec({7, 8}), false).ToCommon();
+    CHECK(!m->IsMaximization() && m->GetConstraintTypes()[1] == CT::GreaterOrEqual);
+}
+TEST(Canonical_Conversions) {                    // Canonical.cpp:199-364
+    Canonical can(CA(), vec({5, 6}), vec({7, 8, 0, 0}), {2, 3}, true);
+    can.SetOriginalVariablesCount(2);
+    auto com = can.ToCommon();                   // original variables only, all '=', all >= 0
+    CHECK(!com->IsMaximization() && com->GetConstraintsMatrix() == SA());
+    CHECK(com->GetConstraintTypes()[0] == CT::Equal && com->GetVariableTypes()[1] == VT::NonNegative);
+    CHECK(com->GetObjectiveCoefficients() == vec({7, 8}) && com->GetRightHandSide() == vec({5, 6}));
+    auto sym = can.ToSymmetrical();              // each row -> (a, b), (-a, -b); sense kept
+    CHECK(!sym->IsMaximization());
+    CHECK(sym->GetConstraintsMatrix() == mat(4, 2, {1, 2, -1, -2, 3, 4, -3, -4}));
+    CHECK(sym->GetRightHandSide() == vec({5, -5, 6, -6}));
+    auto d = can.GetDual();                      // [A^T | -A^T | I], costs [b | -b | 0], rhs c
+    CHECK(d->IsMaximization() && d->GetOriginalVariablesCount() == 4);
+    CHECK(d->GetConstraintsMatrix() == mat(4, 8, {1, 3, -1, -3, 1, 0, 0, 0,
+                                                  2, 4, -2, -4, 0, 1, 0, 0,
+                                                  1, 0, -1, -0.0, 0, 0, 1, 0,
+                                                  0, 1, -0.0, -1, 0, 0, 0, 1}));
+    CHECK(d->GetObjectiveCoefficients() == vec({5, 6, -5, -6, 0, 0, 0, 0}));
+    CHECK(d->GetRightHandSide() == vec({7, 8, 0, 0}));
+    CHECK(d->GetBasisIndices()[0] == 4 && d->GetBasisIndices()[3] == 7);
 }
 
 int main(int argc, char** argv) { return run_all(argc > 1 ? argv[1] : nullptr); }

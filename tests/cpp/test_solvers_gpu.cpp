@@ -3,6 +3,7 @@
 // the simplex solver).
 #include "check.h"
 #include "Canonical.h"
+#include "Common.h"
 #include "EnumerationSolver.h"
 #include "SimplexSolover.h"
 #include "Symmetrical.h"
@@ -101,6 +102,32 @@ TEST(Solver_TwoPhase) {   // SURVEY 8(f) N2; flow of SimplexSolover.h:61-95,331-
     neg.SetOriginalVariablesCount(2);
     VectorXd xn = Solver(neg).twoPhaseSimplex();
     CHECK(xn[0] == 2 && xn[1] == 0);
+}
+TEST(Common_EndToEnd_TwoPhase) {   // N4 + N2: a general-form problem through the whole chain
+    // min 2x1 + 3x2 - x3;  x1 + x2 + x3 >= 4,  x1 + 3x2 = 6,  x1 - x3 <= 5;  x1 >= 0, x2 >= 0, x3 <= 0
+    // (feasible: (3, 1, 0)); the optimum is checked against the enumeration solver, not by hand.
+    using CT = Common::ConstraintType;
+    using VT = Common::VariableType;
+    Common com(mat(3, 3, {1, 1, 1, 1, 3, 0, 1, 0, -1}), vec({4, 6, 5}), vec({2, 3, -1}),
+               {CT::GreaterOrEqual, CT::Equal, CT::LessOrEqual}, {VT::NonNegative, VT::NonNegative, VT::NonPositive}, false);
+    auto can = com.ToCanonical();   // max / <= form with slacks: b has negative entries -> no feasible slack basis
+    auto r = Solver(*can).twoPhaseSimplex_ex();
+    auto e = EnumerationSolver(*can).solve_ex();
+    CHECK(r.status == LP_OPTIMAL);
+    CHECK(std::fabs(r.objective - e.objective) <= 1e-10 * (1 + std::fabs(e.objective)));
+    for (long j = 0; j < r.x.size(); ++j) CHECK(std::fabs(r.x[j] - e.x[j]) <= 1e-9);
+    // back in the original variables: x3 = -x3'; the symmetric form maximises -(c.x)
+    const double x1 = r.x[0], x2 = r.x[1], x3 = -r.x[2];
+    CHECK(x1 >= -1e-9 && x2 >= -1e-9 && x3 <= 1e-9);
+    CHECK(x1 + x2 + x3 >= 4 - 1e-9 && std::fabs(x1 + 3 * x2 - 6) <= 1e-9 && x1 - x3 <= 5 + 1e-9);
+    VectorXd xo(3);
+    xo[0] = x1; xo[1] = x2; xo[2] = x3;
+    CHECK(std::fabs(com.Evaluate(xo) + r.objective) <= 1e-9);
+    // the same chain reports an infeasible general-form problem (x1 - x3 <= 2 contradicts the rest)
+    Common bad(mat(3, 3, {1, 1, 1, 1, 3, 0, 1, 0, -1}), vec({4, 6, 2}), vec({2, 3, -1}),
+               {CT::GreaterOrEqual, CT::Equal, CT::LessOrEqual}, {VT::NonNegative, VT::NonNegative, VT::NonPositive}, false);
+    CHECK(Solver(*bad.ToCanonical()).twoPhaseSimplex_ex(false).status == LP_INFEASIBLE);
+    CHECK_THROWS(EnumerationSolver(*bad.ToCanonical()).solve(), std::runtime_error);
 }
 TEST(Enumeration_MultiGpuShardsOnOneDevice) {
     // n_gpus = 1 path vs the sharded host-thread path cannot be exercised with >1 device here;
