@@ -180,6 +180,71 @@ __device__ int block_scan_keyed(Red& R, int count, double eps, double& best, Get
     return sel;
 }
 
+// The same scan done by ONE wave (the tableaus of this kernel have a few hundred rows/columns at
+// most: two or three entries per lane).  No LDS scratch, no barriers; the caller publishes the
+// result to the other waves.  Entries are re-read through get() on every pass.
+template <bool WANT_MAX, typename Get>
+__device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    const int lane = threadIdx.x & 63;
+    double lv = sentinel;
+    int lkey = INT_MAX, lslot = -1;
+    for (int s = lane; s < count; s += 64) {
+        double v;
+        int k;
+        bool ok;
+        get(s, v, k, ok);
+        if (ok && ((WANT_MAX ? (v > lv) : (v < lv)) || (v == lv && k < lkey))) {
+            lv = v;
+            lkey = k;
+            lslot = s;
+        }
+    }
+    const double M = lpdev::wave_ext_f64<WANT_MAX>(lv);
+    const int jM = lpdev::wave_min_i32((lv == M && lv != sentinel) ? lkey : INT_MAX);
+    best = sentinel;
+    if (jM == INT_MAX) return -1;
+    const unsigned long long hit = __ballot(lv == M && lkey == jM);
+    const int sM = __builtin_amdgcn_readlane(lslot, (int)__builtin_ctzll(hit));
+    double lp = sentinel;
+    for (int s = lane; s < count; s += 64) {
+        double v;
+        int k;
+        bool ok;
+        get(s, v, k, ok);
+        if (ok && k < jM) lp = lpdev::ext2<WANT_MAX>(lp, v);
+    }
+    const double P = lpdev::wave_ext_f64<WANT_MAX>(lp);
+    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+        best = M;
+        return sM;
+    }
+    // near-tie: replay the chain jump by jump (see block_scan_keyed)
+    int sel = -1;
+    for (;;) {
+        const double thr = WANT_MAX ? best + eps : best - eps;
+        int ck = INT_MAX, cs = -1;
+        double cv = 0.0;
+        for (int s = lane; s < count; s += 64) {
+            double v;
+            int k;
+            bool ok;
+            get(s, v, k, ok);
+            if (ok && (WANT_MAX ? (v > thr) : (v < thr)) && k < ck) {
+                ck = k;
+                cv = v;
+                cs = s;
+            }
+        }
+        const int kmin = lpdev::wave_min_i32(ck);
+        if (kmin == INT_MAX) break;
+        const int src = (int)__builtin_ctzll(__ballot(ck == kmin));
+        best = lpdev::wave_bcast_f64(cv, src);
+        sel = __builtin_amdgcn_readlane(cs, src);
+    }
+    return sel;
+}
+
 __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = d.m, n = d.n, nn = n - m, W = nn + 1, pitch = d.pitch;
@@ -194,7 +259,6 @@ __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
     int* slotvar = reinterpret_cast<int*>(ratio + m); // nn : variable held by each slot
     int* basis = slotvar + nn;                        // m  : N by position
     int* posofvar = basis + m;                        // n  : scratch for the initial split
-    Red R{rs, 0, tid & 63, tid >> 6, nt >> 6};
 
     const double* A = d.A + (size_t)lp * m * n;
     const double* b = d.b + (size_t)lp * m;
@@ -232,45 +296,53 @@ __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
     const int i0 = tid / W, j0 = tid - i0 * W;
     const int total = (m + 1) * W;
 
+    const int wave = tid >> 6, lane = tid & 63;
+    int* pub = &rs->a[0][0];   // [0] entering slot, [1] leaving position, published by wave 0
     while (true) {
         if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
             status = LP_ITER_LIMIT;
             break;
         }
-        // ---- pricing over the non-basic slots, keyed by variable index (:152-174)
-        double best;
-        const double* drow = T + (size_t)m * pitch;
-        auto getd = [&](int s, double& v, int& k, bool& ok) {
-            v = drow[s];
-            k = slotvar[s];
-            ok = true;
-        };
-        const int se = d.maximize ? block_scan_keyed<true>(R, nn, eps, best, getd)
-                                  : block_scan_keyed<false>(R, nn, eps, best, getd);
-        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
-        if (optimal || se < 0) {
+        // ---- pricing over the non-basic slots, keyed by variable index (:152-174): wave 0 alone
+        if (wave == 0) {
+            double best;
+            const double* drow = T + (size_t)m * pitch;
+            auto getd = [&](int s, double& v, int& k, bool& ok) {
+                v = drow[s];
+                k = slotvar[s];
+                ok = true;
+            };
+            int se = d.maximize ? wave_scan_keyed<true>(nn, eps, best, getd)
+                                : wave_scan_keyed<false>(nn, eps, best, getd);
+            const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
+            if (optimal) se = -1;
+            if (lane == 0) pub[0] = se;
+        }
+        __syncthreads();
+        const int se = pub[0];
+        if (se < 0) {
             status = LP_OPTIMAL;
             break;
         }
-        // ---- entering column, unbounded test (:176-179), ratios (:185-186)
-        int any_pos = 0;
-        for (int i = tid; i < m; i += nt) {
-            const double ui = T[(size_t)i * pitch + se];
-            ratio[i] = (ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
-            if (!(ui <= eps)) any_pos = 1;
+        // ---- entering column, unbounded test (:176-179), ratios (:185-186) and the ratio test
+        // keyed by basis position (:181-194; +inf entries are never taken): wave 0 alone
+        if (wave == 0) {
+            int any_pos = 0;
+            for (int i = lane; i < m; i += 64)
+                if (!(T[(size_t)i * pitch + se] <= eps)) any_pos = 1;
+            double theta;
+            auto getr = [&](int i, double& v, int& k, bool& ok) {
+                const double ui = T[(size_t)i * pitch + se];
+                v = (ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
+                k = i;
+                ok = true;
+            };
+            int r = wave_scan_keyed<false>(m, eps, theta, getr);
+            if (!__any(any_pos)) r = -1;
+            if (lane == 0) pub[1] = r;
         }
-        if (!__syncthreads_or(any_pos)) {
-            status = LP_UNBOUNDED;
-            break;
-        }
-        // ---- ratio test keyed by basis position (:181-194); +inf entries are never taken
-        double theta;
-        auto getr = [&](int i, double& v, int& k, bool& ok) {
-            v = ratio[i];
-            k = i;
-            ok = true;
-        };
-        const int r = block_scan_keyed<false>(R, m, eps, theta, getr);
+        __syncthreads();
+        const int r = pub[1];
         if (r < 0) {
             status = LP_UNBOUNDED;
             break;
@@ -282,25 +354,43 @@ __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
         for (int i = tid; i <= m; i += nt)
             lcol[i] = (i == r) ? inv : -T[(size_t)i * pitch + se] / ur;
         __syncthreads();
-        // ---- rank-1 update of every stored element; slot se receives the leaving column
+        // ---- rank-1 update of every stored element; slot se receives the leaving column.
+        // Four elements per thread and step, so that their LDS reads are in flight together.
         {
             int i = i0, j = j0;
-            for (int idx = tid; idx < total; idx += nt) {
-                double* p = T + (size_t)i * pitch + j;
-                const double l = lcol[i];
-                double t;
-                if (j == se)
-                    t = l;
-                else if (i == r)
-                    t = prow[j] * l;
-                else
-                    t = fma(l, prow[j], *p);
-                *p = t;
-                i += step_i;
-                j += step_j;
-                if (j >= W) {
-                    j -= W;
-                    ++i;
+            for (int idx = tid; idx < total; idx += 4 * nt) {
+                int ii[4], jj[4];
+                bool ok[4];
+                double l[4], pr[4], old[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ii[u] = i;
+                    jj[u] = j;
+                    ok[u] = idx + u * nt < total;
+                    i += step_i;
+                    j += step_j;
+                    if (j >= W) {
+                        j -= W;
+                        ++i;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ic = ok[u] ? ii[u] : 0, jc = ok[u] ? jj[u] : 0;
+                    l[u] = lcol[ic];
+                    pr[u] = prow[jc];
+                    old[u] = T[(size_t)ic * pitch + jc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double t;
+                    if (jj[u] == se)
+                        t = l[u];
+                    else if (ii[u] == r)
+                        t = pr[u] * l[u];
+                    else
+                        t = fma(l[u], pr[u], old[u]);
+                    if (ok[u]) T[(size_t)ii[u] * pitch + jj[u]] = t;
                 }
             }
         }
