@@ -310,8 +310,8 @@ def main():
                 "workload": f"vertex enumeration C({n},{m})={total} subsets, dense random LP "
                             f"seed 0 (BASELINE configs[3]); rank space sharded over {world} GPU(s)",
                 "enum_algo": args.enum_algo, "subsets_per_gpu": shard,
-                "parallelism": f"cost-balanced rank-range shards x{world}, all-reduce(max)+"
-                               "all-reduce(min) of the incumbent",
+                "parallelism": f"cost-balanced rank-range shards x{world}, one all-gather of the "
+                               "incumbent record (score, rank, counts) per step",
             },
             "enum": {
                 "optimum": None if winner is None else winner["obj"],

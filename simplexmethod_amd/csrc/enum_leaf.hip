@@ -42,20 +42,24 @@ constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so th
 
 // One subset, one lane.  tab: the node's tableau, column q (stride STRIDE doubles) = the q-th
 // selectable column, column R = the rhs; c[]: the KD chosen columns; U[]: the KD rows not used by
-// the prefix, ascending; used: mask of the rows the prefix did use.  UNIFORM: tab / U / used are
-// the same in every lane of the wave (the phase 2 loop then runs on scalar registers).
-// Returns 0 feasible, 1 infeasible, 2 singular.
-template <int KD, int STRIDE, bool UNIFORM>
+// the prefix, ascending; used: mask of the rows the prefix did use.  PERM: the tableau's rows were
+// permuted when it was written — the KD unused rows (ascending) sit at positions 0..KD-1 and the
+// used ones at KD..m-1 — so every row index below is a compile-time constant (LDS reads with
+// immediate offsets, pairs of rows per instruction) and U / used are ignored; the wave is then
+// uniform (one tableau per wave).  Returns 0 feasible, 1 infeasible, 2 singular.
+template <int KD, int STRIDE, bool PERM>
 __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
                                             unsigned used, double minp0, double maxp0, int m) {
     // ---- phase 1: unused rows x chosen columns
     double E[KD][KD], H[KD];
 #pragma unroll
-    for (int r = 0; r < KD; ++r) {
+    for (int t = 0; t < KD; ++t) {
+        const double* col = tab + c[t] * STRIDE;
 #pragma unroll
-        for (int t = 0; t < KD; ++t) E[r][t] = tab[c[t] * STRIDE + U[r]];
-        H[r] = tab[R * STRIDE + U[r]];
+        for (int r = 0; r < KD; ++r) E[r][t] = col[PERM ? r : U[r]];
     }
+#pragma unroll
+    for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + (PERM ? r : U[r])];
     // Invariant: before step t, rows t..KD-1 of E are the rows not yet used, in ascending
     // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
     // are the pivot rows of steps 0..t-1.  The chosen row p is ROTATED into position t
@@ -66,21 +70,16 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     bool sing = false;
 #pragma unroll
     for (int t = 0; t < KD - 2; ++t) {
-        double big = -1.0, piv = 0.0;
+        // first row of largest |entry| (a NaN entry is never the maximum: fmax drops it)
+        double big = -1.0;
+#pragma unroll
+        for (int r = t; r < KD; ++r) big = fmax(big, fabs(E[r][t]));
         int p = t;
 #pragma unroll
-        for (int r = t; r < KD; ++r) {
-            const double a = fabs(E[r][t]);
-            const bool take = a > big;   // strict: ties keep the first (lowest) row
-            big = take ? a : big;
-            piv = take ? E[r][t] : piv;
-            p = take ? r : p;
-        }
+        for (int r = KD - 1; r >= t; --r) p = (fabs(E[r][t]) == big) ? r : p;   // descending: the first wins
         if (!(big > 0.0)) sing = true;
         minp = fmin(minp, big);
         maxp = fmax(maxp, big);
-        const double inv = 1.0 / piv;
-        INV[t] = inv;
         // rotate row p to position t (columns t..KD-1 and the rhs)
 #pragma unroll
         for (int cc = t; cc <= KD; ++cc) {
@@ -99,6 +98,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
             }
             if (cc < KD) E[t][cc < KD ? cc : 0] = pr; else H[t] = pr;
         }
+        const double inv = 1.0 / E[t][t];   // the pivot element, now in its static position
+        INV[t] = inv;
 #pragma unroll
         for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
         PRH[t] = H[t];
@@ -161,12 +162,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         feas = feas && (!has || x >= -1e-9);
         alive = alive && feas;
     };
-    if constexpr (UNIFORM) {
-        while (rows && __any(alive)) {
-            const int i = __builtin_ctz(rows);
-            rows &= rows - 1u;
-            one_row(i, true);
-        }
+    if constexpr (PERM) {
+        for (int i = KD; i < m && __any(alive); ++i) one_row(i, true);
     } else {
         while (__any(alive && rows != 0u)) {
             const bool has = rows != 0u;
@@ -373,30 +370,29 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             const double inv = 1.0 / pcol[p];
             const bool isp = (r == p);
             const double lx = isp ? inv : -(w * inv);
+            umask |= 1u << p;
+            // The child's rows are written PERMUTED: the 6 rows still unused (ascending) at positions
+            // 0..5, the used ones (ascending) behind them — leaf_verdict<PERM> then reads every row at
+            // a compile-time offset.
+            const unsigned all = (1u << m) - 1u, below = (1u << r) - 1u, freem = ~umask & all;
+            const int pos = (r >= m) ? r
+                            : ((freem >> r) & 1u) ? __builtin_popcount(freem & below)
+                                                  : __builtin_popcount(freem) + __builtin_popcount(umask & all & below);
             double* ctab = s_child[wave];
 #pragma unroll
             for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
                 const int j = g + 4 * q;            // child column j = column child+1+j (j = R: rhs)
                 if (j <= R) {
                     const double* pc = tab + (child + 1 + j - D) * TS;
-                    ctab[j * TS + r] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
+                    ctab[j * TS + pos] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
                 }
             }
-            umask |= 1u << p;
             tab = ctab;
         } else {
             tab += (last + 1 - D) * TS;              // column q below = column last+1+q
+            // (m = 6: the root record, no row used yet — the identity is the permuted order)
         }
-        // rows: the 6 not used by the prefix (ascending), and the used ones
-        int U[KD];
-        {
-            unsigned free_rows = ~umask & ((1u << m) - 1u);
-#pragma unroll
-            for (int r = 0; r < KD; ++r) {
-                U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
-                free_rows &= free_rows - 1u;
-            }
-        }
+        const int U[KD] = {0, 1, 2, 3, 4, 5};        // unused by leaf_verdict<PERM>
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
             if (rank < begin || rank >= end) continue;

@@ -1,10 +1,10 @@
 """One-process-per-GPU vertex enumeration: rank-range sharding + the incumbent reduce.
 
 SURVEY.md §8(e): the combination-rank space [0, C(n,m)) is cut into `world` contiguous
-equal ranges; each process enumerates its range on its own GPU (no data-path collective);
-the only exchange is the incumbent optimum: all-reduce(max) of the best score (8 bytes over
-RCCL/xGMI, latency-bound), then all-reduce(min) of the smallest rank within 1e-9 of it
-(the shard-independent tie rule of SURVEY.md §8 row E1), then a sum of the counts.
+ranges; each process enumerates its range on its own GPU (no data-path collective); the only
+exchange is the incumbent optimum: one all-gather of (best score, smallest rank within 1e-9 of
+it, counts) over RCCL/xGMI, latency-bound, and — only for near-ties across shards — an
+all-reduce(min) of recomputed ranks (the shard-independent tie rule of SURVEY.md §8 row E1).
 
 The collectives are passed in as callables so that the same driver runs over
 torch.distributed (nccl == RCCL on ROCm, or gloo in the CPU tests) or, for world == 1,
@@ -51,7 +51,7 @@ def _lexrank(universe, subset):
     return r
 
 
-RECORD_COST = 180  # one depth m-7 tree node costs about as much as 180 subsets (scripts/scan_record_cost.py, MI355X)
+RECORD_COST = 190  # one depth m-7 tree node costs about as much as 190 subsets (scripts/scan_record_cost.py, MI355X)
 
 
 def balanced_shard_bounds(n, m, rank, world, record_cost=RECORD_COST):
@@ -106,6 +106,9 @@ class LocalComm:
     def sum_i64(self, a):
         return a
 
+    def gather_i64(self, a):
+        return [list(a)]
+
     def barrier(self):
         pass
 
@@ -138,8 +141,23 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [int(v) for v in t.tolist()]
 
+    def gather_i64(self, a):
+        """all-gather of a short int64 record: one collective, one host sync."""
+        t = self.torch.tensor(list(a), dtype=self.torch.int64, device=self.device)
+        out = self.torch.empty(self.world * t.numel(), dtype=self.torch.int64, device=self.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.view(self.world, t.numel()).tolist()
+
     def barrier(self):
         self.dist.barrier()
+
+
+def _f64_bits(v):
+    return int(np.array([v], dtype=np.float64).view(np.int64)[0])
+
+
+def _bits_f64(b):
+    return float(np.array([b], dtype=np.int64).view(np.float64)[0])
 
 
 def enum_solve_sharded(comm, total, maximize, range_fn, first_fn, bounds=None):
@@ -151,17 +169,38 @@ def enum_solve_sharded(comm, total, maximize, range_fn, first_fn, bounds=None):
             balanced_shard_bounds(n, m, rank, world) for the cost-balanced cut
     Returns dict(feasible, zstar, rank, counts) — identical on every process and for every
     `world` (the tie rule does not depend on how the range was cut).
+
+    ONE collective in the common case: every process applies the tie rule against its OWN best
+    score and all-gathers (score, that rank, counts).  The global optimum is the largest score; a
+    process whose own best IS the optimum has already applied the rule against the right value,
+    so the answer is the smallest of those ranks.  Only if another process's best lies within the
+    tolerance below the optimum without being equal to it (two distinct vertices within 1e-9 of
+    each other in different shards) are its candidates recomputed against the optimum and reduced
+    with a second collective — every process sees the same gathered records, so all take the
+    same branch.
     """
     lo, hi = bounds if bounds is not None else shard_bounds(total, comm.rank, comm.world)
     z, counts = range_fn(lo, hi)
     score = z if maximize else -z
     if np.isnan(score):
         score = -np.inf
-    gscore = comm.max_f64(score)
-    gcounts = comm.sum_i64(counts)
+    local_first = U64_MAX
+    if score != -np.inf:
+        local_first = first_fn(lo, hi, z, TIE_TOL)
+    rec = [_f64_bits(score), min(local_first, (1 << 63) - 1)] + [int(c) for c in counts]
+    allrec = comm.gather_i64(rec)
+    scores = [_bits_f64(r[0]) for r in allrec]
+    gcounts = [sum(r[2 + k] for r in allrec) for k in range(3)]
+    gscore = max(scores)
     if gscore == -np.inf:
         return dict(feasible=False, zstar=None, rank=None, counts=gcounts)
     zstar = gscore if maximize else -gscore
-    local_first = first_fn(lo, hi, zstar, TIE_TOL) if score >= gscore - TIE_TOL else U64_MAX
-    grank = comm.min_u64(local_first)
+    exact = [r[1] for r, s in zip(allrec, scores) if s == gscore]
+    near = any(gscore - TIE_TOL <= s < gscore for s in scores)
+    if not near:
+        grank = min(exact)
+    else:  # rare: redo the tie rule against the global optimum where it can matter
+        redo = first_fn(lo, hi, zstar, TIE_TOL) if score >= gscore - TIE_TOL else U64_MAX
+        grank = comm.min_u64(redo)
+    grank = U64_MAX if grank >= (1 << 63) - 1 else grank
     return dict(feasible=True, zstar=zstar, rank=grank, counts=gcounts)

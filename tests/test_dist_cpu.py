@@ -113,3 +113,74 @@ def test_balanced_shard_bounds_cover_and_match_oracle_ranking():
     assert sizes[0] > sizes[-1]
     # small trees keep the equal-size cut
     assert lpdist.balanced_shard_bounds(12, 5, 1, 2) == lpdist.shard_bounds(o.binom(12, 5), 1, 2)
+
+
+class _ThreadComm:
+    """Two (or more) simulated processes in threads: enough to drive both branches of
+    enum_solve_sharded's exchange without a process group."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self.s = rank, world, shared
+
+    def _exchange(self, key, value, combine):
+        import threading
+        with self.s["lock"]:
+            self.s.setdefault(key, {})[self.rank] = value
+        self.s["barrier"].wait()
+        vals = [self.s[key][r] for r in range(self.world)]
+        self.s["barrier"].wait()
+        return combine(vals)
+
+    def gather_i64(self, a):
+        self.s["collectives"][self.rank] += 1
+        return self._exchange("g", list(a), lambda v: v)
+
+    def min_u64(self, v):
+        self.s["collectives"][self.rank] += 1
+        return self._exchange("m", v, min)
+
+
+def _run_threads(entries, total, world, maximize=True):
+    """entries: {rank: score}.  Returns (results per process, collectives per process)."""
+    import threading
+    from simplexmethod_amd import dist as lpdist
+
+    def range_fn(lo, hi):
+        inside = [s for r, s in entries.items() if lo <= r < hi]
+        best = (max(inside) if maximize else min(inside)) if inside else (-np.inf if maximize else np.inf)
+        return best, [len(inside), (hi - lo) - len(inside), 0]
+
+    def first_fn(lo, hi, z, tol):
+        ok = [r for r, s in entries.items() if lo <= r < hi and ((s >= z - tol) if maximize else (s <= z + tol))]
+        return min(ok) if ok else lpdist.U64_MAX
+
+    shared = dict(lock=threading.Lock(), barrier=threading.Barrier(world), collectives=[0] * world)
+    out = [None] * world
+
+    def work(r):
+        out[r] = lpdist.enum_solve_sharded(_ThreadComm(r, world, shared), total, maximize, range_fn, first_fn)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    return out, shared["collectives"]
+
+
+def test_exchange_single_collective_and_near_tie_branch():
+    # unique optimum: one collective, the winner's own tie rule is already the answer
+    out, coll = _run_threads({3: 9.0, 5: 9.5, 12: 10.0, 14: 10.0 - 2e-10}, 16, 2)
+    assert all(o == dict(feasible=True, zstar=10.0, rank=12, counts=[4, 12, 0]) for o in out)
+    assert coll == [1, 1]
+    # a different vertex within 1e-9 of the optimum sits in the OTHER shard at a smaller rank:
+    # the tie rule must pick it, which needs the second round
+    out, coll = _run_threads({3: 10.0 - 5e-10, 5: 9.0, 12: 10.0}, 16, 2)
+    assert all(o["rank"] == 3 and o["zstar"] == 10.0 for o in out)
+    assert coll == [2, 2]
+    # minimisation mirrors it; three shards; an empty shard
+    out, coll = _run_threads({1: 4.0, 9: 4.0 + 3e-10, 10: 7.0}, 18, 3, maximize=False)
+    assert all(o["rank"] == 1 and o["zstar"] == 4.0 and o["counts"] == [3, 15, 0] for o in out)
+    # nothing feasible anywhere
+    out, coll = _run_threads({}, 8, 2)
+    assert all(o["feasible"] is False and o["counts"] == [0, 8, 0] for o in out)
