@@ -37,6 +37,7 @@ constexpr int POOLC = 20;         // LDS columns (16 doubles each) per group for
 constexpr int MAXMU = 10;         // mu descriptors per group per round
 constexpr int SWEEP_THREADS = 256;
 constexpr int SWEEP_GROUPS = SWEEP_THREADS / PG;
+constexpr int kExpandParents = 64;  // parents per block of k_enum_expand (one slot allocation per block)
 constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
 
 // ---------------------------------------------------------------------------
@@ -44,51 +45,94 @@ constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
                                                      const double* __restrict__ src, int src_cap,
-                                                     double* __restrict__ dst, int dst_cap,
+                                                     double* __restrict__ dst, int dst_cap, int ppw,
                                                      unsigned long long begin,
                                                      unsigned long long end) {
+    // A block owns 4 * ppw consecutive parents (ppw = parents per wave, 1..16: 16 on wide levels,
+    // fewer on levels that could not fill the chip otherwise).  Phase A: one lane per parent counts the
+    // children whose rank interval meets [begin, end) and the block takes all their slots with ONE
+    // atomic — a returning atomic on one word costs ~11 ns chip-wide, and at one per wave of four
+    // parents (184 k of them for the 735 k parents of C(32,16)'s last level) that alone was 2 ms.
+    // Phase B: one WAVE per parent, 16 parents per wave in turn: its four 16-lane groups
+    // (lane = row) pivot four different children at a time, so a parent's up to n-m+1 children
+    // take 5 rounds of dependent HBM round trips instead of 17, with four children's stores in
+    // flight together.
+    __shared__ int s_base[kExpandParents];
     const int m = d.m, n = d.n;
-    const int gl = threadIdx.x & (PG - 1);
-    const int lane = threadIdx.x & 63, gbase = lane & ~(PG - 1);
-    const int node = blockIdx.x * (blockDim.x / PG) + (threadIdx.x / PG);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, gl = lane & (PG - 1), g = lane >> 4, gbase = lane & ~(PG - 1);
     // the level's record count lives on the device (level_counts[t]): the host queues all levels
-    // without synchronising, with grids sized for the combinatorial upper bound
+    // without synchronising, with grids sized for an upper bound
     const int nsrc = min(pd.level_counts[t], src_cap);  // (an overflowed level is reported by the host)
-    if (blockIdx.x * (blockDim.x / PG) >= nsrc) return;  // whole block beyond the level
-    const double* P = src + (size_t)(node < nsrc ? node : 0) * rec_doubles(n, t);
-    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
-    const bool valid = node < nsrc && pm.last_col != kHole;
+    const int first = blockIdx.x * 4 * ppw;
+    if (first >= nsrc) return;
     const int lim = n - m + t;  // largest column selectable at depth t
-    // ---- children whose rank interval meets [begin, end): one slot each, allocated with a
-    // single atomic per WAVE (a per-child atomic on one counter serialises the whole level)
-    int nchild = 0;
-    if (valid) {
-        unsigned long long rbc = pm.rank_base;
-        for (int a = pm.last_col + 1; a <= lim; ++a) {
-            const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
-            if (overlap(rbc, cnt, begin, end) != 0ULL) ++nchild;
-            rbc += cnt;
+    if (tid < 64) {
+        const int node = first + tid;
+        int nch = 0;
+        if (tid < 4 * ppw && node < nsrc) {
+            const NodeMeta* q = reinterpret_cast<const NodeMeta*>(src + (size_t)node * rec_doubles(n, t) +
+                                                                  (size_t)PG * (n - t + 1));
+            const int last = q->last_col;
+            if (last != kHole) {
+                unsigned long long rb = q->rank_base;
+                for (int a = last + 1; a <= lim; ++a) {
+                    const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
+                    if (overlap(rb, cnt, begin, end) != 0ULL) ++nch;
+                    rb += cnt;
+                }
+            }
         }
+        int incl = nch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&pd.level_counts[t + 1], total);
+        base = __shfl(base, 63, 64);
+        s_base[tid] = base + incl - nch;
     }
-    const int g0 = __shfl(nchild, 0, 64), g1 = __shfl(nchild, 16, 64), g2 = __shfl(nchild, 32, 64),
-              g3 = __shfl(nchild, 48, 64);
-    int wbase = 0;
-    if (lane == 0 && g0 + g1 + g2 + g3 > 0) wbase = atomicAdd(&pd.level_counts[t + 1], g0 + g1 + g2 + g3);
-    wbase = __shfl(wbase, 0, 64);
-    const int gidx = lane >> 4;
-    int slot = wbase + (gidx > 0 ? g0 : 0) + (gidx > 1 ? g1 : 0) + (gidx > 2 ? g2 : 0);
-    if (!valid) return;  // whole group leaves together (no wave-level operation below)
+    __syncthreads();
+    for (int it = 0; it < ppw; ++it) {
+    const int local = (tid >> 6) * ppw + it;
+    const int node = first + local;
+    if (node >= nsrc) break;
+    const double* P = src + (size_t)node * rec_doubles(n, t);
+    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
+    if (pm.last_col == kHole) continue;
+    // ---- the children, one per lane: subset counts, rank bases (exclusive scan), range overlap
+    const int a_l = pm.last_col + 1 + lane;
+    const unsigned long long cnt_l = (a_l <= lim) ? binom(d, n - 1 - a_l, m - t - 1) : 0ULL;
+    unsigned long long incl = cnt_l;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {   // at most NMX + 1 = 17 children
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    const unsigned long long rb_l = pm.rank_base + (incl - cnt_l);
+    const unsigned long long ov_l = overlap(rb_l, cnt_l, begin, end);
+    const unsigned long long vmask = __ballot(ov_l != 0ULL);
+    const int nchild = __popcll(vmask);
+    if (nchild == 0) continue;
+    const int wbase = s_base[local];
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
     const double prhs = P[(size_t)(n - t) * PG + gl];
-    unsigned long long rb = pm.rank_base;
     unsigned long long sing = 0ULL;
-    for (int a = pm.last_col + 1; a <= lim; ++a) {
-        const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
-        const unsigned long long ov = overlap(rb, cnt, begin, end);
-        const unsigned long long rb_child = rb;
-        rb += cnt;
-        if (ov == 0ULL) continue;
-        const int myslot = slot++;
+    for (int k0 = 0; k0 < nchild; k0 += 4) {
+        const int k = k0 + g;                  // this group's child (k-th valid one)
+        const bool active = k < nchild;        // whole groups are active or not
+        unsigned long long vm = vmask;
+        for (int i = 0; i < (active ? k : 0); ++i) vm &= vm - 1ULL;
+        const int src_lane = active ? (int)__builtin_ctzll(vm) : 0;
+        const int a = pm.last_col + 1 + src_lane;
+        const unsigned long long rb_child = __shfl(rb_l, src_lane, 64);
+        const unsigned long long ov = __shfl(ov_l, src_lane, 64);
+        const int myslot = wbase + k;
+        // (no wave-level operation below: groups proceed independently)
+        if (!active) continue;
         if (myslot >= dst_cap) {
             if (gl == 0) atomicExch(pd.overflow, 1);
             continue;
@@ -124,11 +168,12 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             cm.maxp = maxp;
             cm.last_col = a;
             cm.used_mask = pm.used_mask | (1u << p);
-            for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+            for (int q = 0; q < 8; ++q) cm.pad[q] = 0;
             *cmeta = cm;
         }
     }
     if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
+    }
 }
 
 // The same expansion for NARROW levels (the first few, and every level of a small rank range):
@@ -744,7 +789,9 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         caps[t + 1] = cap;
         // parents of this level inside the range (exact; the level's holes are among them)
         const uint64_t bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, t), 0x7FFFFFFFULL);
-        const int groups_per_block = 256 / PG;
+        // k_enum_expand: 4 * ppw parents per block; ppw = 16 once that still leaves 32 waves per CU
+        const int ppw = (int)std::max<uint64_t>(1, std::min<uint64_t>(kExpandParents / 4, bound / ((uint64_t)ctx->num_cus * 32)));
+        const int groups_per_block = 4 * ppw;
         // narrow levels: one wave per (parent, child)
         const uint64_t waves = bound * (uint64_t)(n - m + 1);
         if (waves <= (uint64_t)ctx->num_cus * 128)
@@ -753,7 +800,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
                                (unsigned long long)begin, (unsigned long long)end);
         else
             hipLaunchKernelGGL(k_enum_expand, (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block), 256, 0, s,
-                               d, pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
+                               d, pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap, ppw,
                                (unsigned long long)begin, (unsigned long long)end);
         ++launches;
         cur = nxt;
