@@ -487,8 +487,8 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6);
-    (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.item_count);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6); (void)hipFree(p->dcomb5);
+    (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.items2); (void)hipFree(p->prefix.item_count);
     if (p->h_item_count) (void)hipHostFree(p->h_item_count);
     (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
     if (p->h_level_counts) (void)hipHostFree(p->h_level_counts);
@@ -560,7 +560,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
                 for (int qb = qa + 1; qb < R; ++qb) pairtab[(size_t)R * kPairTabStride + r++] = (unsigned short)(qa | (qb << 8));
         }
         LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
-        LP_TRY(hipMalloc(&pd.item_count, sizeof(int)));
+        LP_TRY(hipMalloc(&pd.item_count, 2 * sizeof(int)));
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
         LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
@@ -592,8 +592,27 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         }
         LP_TRY(hipMalloc(&p->dcomb6, sizeof(unsigned) * comb6.size()));
         LP_TRY(hipMemcpyAsync(p->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
-        LP_TRY(hipStreamSynchronize(s));  // comb6 is a local
+        // second level of the leaf kernel: every 5-subset of R <= 21 columns, same packing
+        std::vector<unsigned> comb5(32, 0u);
+        for (int R = 5; R <= 21; ++R) {
+            comb5[(size_t)R] = (unsigned)comb5.size();
+            int s5[5] = {0, 1, 2, 3, 4};
+            for (;;) {
+                unsigned pk = 0;
+                for (int t = 0; t < 5; ++t) pk |= (unsigned)s5[t] << (5 * t);
+                comb5.push_back(pk);
+                int t = 4;
+                while (t >= 0 && s5[t] == R - 5 + t) --t;
+                if (t < 0) break;
+                ++s5[t];
+                for (int u = t + 1; u < 5; ++u) s5[u] = s5[u - 1] + 1;
+            }
+        }
+        LP_TRY(hipMalloc(&p->dcomb5, sizeof(unsigned) * comb5.size()));
+        LP_TRY(hipMemcpyAsync(p->dcomb5, comb5.data(), sizeof(unsigned) * comb5.size(), hipMemcpyHostToDevice, s));
+        LP_TRY(hipStreamSynchronize(s));  // comb6 / comb5 are locals
         pd.comb6 = p->dcomb6;
+        pd.comb5 = p->dcomb5;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

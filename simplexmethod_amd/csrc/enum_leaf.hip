@@ -36,6 +36,8 @@ namespace {
 
 constexpr int LEAF_THREADS = 256;
 constexpr int LEAF_WAVES = LEAF_THREADS / 64;
+constexpr int kGrandMin = 10;         // a depth m-5 node with >= 10 selectable columns (>= 252 subsets) is
+                                      // finished by the two-level kernel (second in-LDS pivot, 5 columns per lane)
 constexpr int THIN_TAIL = 8;          // the thin kernel takes the subsets inside the last 8 columns
 constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
                                       // same row of different columns hit different banks
@@ -177,13 +179,20 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
 
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
 
-// Work items of the leaf kernel: (record, child column, chunk of kChunk subsets, rank offset of the
-// child inside the record), so that no item is longer than 16 wave passes — a depth m-6 node can
-// hold up to C(22,6) = 74,613 subsets, and a rank-range shard of an 8-GPU run is only a few
-// milliseconds of work in total.  One lane per record; slots in the item table are allocated with
-// one atomic per wave.  FUSED: records are depth m-7 nodes and an item names one of their children
-// (those with at least min_child_R selectable columns; the thin kernel takes the rest);
-// otherwise (m = 6) the one record is the depth m-6 root itself.
+// Work items of the leaf kernels, so that no item is longer than 16 wave passes — a depth m-6 node
+// can hold up to C(22,6) = 74,613 subsets, and a rank-range shard of an 8-GPU run is only a few
+// milliseconds of work in total.  One lane per record; slots in the item tables are allocated with
+// one atomic per wave and table.  FUSED: records are depth m-7 nodes; for each child a (with at
+// least min_child_R selectable columns; the thin kernel takes the rest) whose subsets meet
+// [begin, end):
+//   table 1 (k_enum_leaves<2>): the child's subsets are grouped by their first remaining column
+//     j2 (lexicographic order); every group that leaves at least kGrandMin selectable columns is
+//     cut into items (record, a | j2 << 8 | groups << 16, first subset of the chunk inside the
+//     group, rank offset of the group inside the record) — a large group in chunks of kChunk, or
+//     several consecutive small groups packed into one item;
+//   table 0 (k_enum_leaves<1>): the child's remaining subsets — (record, a, first subset of the
+//     chunk inside the child, rank offset of the child inside the record).
+// !FUSED (m = 6): the one record is the depth m-6 root itself, table 0 only.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd,
                                                          const double* __restrict__ roots,
@@ -191,11 +200,19 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
                                                          unsigned long long begin,
                                                          unsigned long long end) {
     constexpr int KD = 6;
+    // C(r, 5) and C(r, 6) for r <= NMX + KD + 1, from LDS (the loops below are chains of dependent
+    // lookups; out of L2 they were half of this kernel's time)
+    __shared__ unsigned int s_b5[NMX + KD + 2], s_b6[NMX + KD + 2];
+    if (threadIdx.x < NMX + KD + 2) {
+        s_b5[threadIdx.x] = (unsigned int)d.binom[threadIdx.x * kBinomK + KD - 1];
+        s_b6[threadIdx.x] = (unsigned int)d.binom[threadIdx.x * kBinomK + KD];
+    }
+    __syncthreads();
     const int n = d.n, m = d.m, D = m - KD - (FUSED ? 1 : 0);
     const int nroots = min(pd.level_counts[root_level], root_cap);
     const int rec = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int nch = 0, last = kHole;
+    int last = kHole;
     unsigned long long rb0 = 0ULL;
     if (rec < nroots) {
         const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(roots + (size_t)rec * rec_doubles(n, D) +
@@ -203,74 +220,116 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
         last = pm->last_col;
         rb0 = pm->rank_base;
     }
-    // children a (FUSED) or the node itself: chunks whose rank interval meets [begin, end)
-    auto visit = [&](auto&& emit) {
+    // chunks of [lo0, hi0) (subset indices relative to `base`) whose rank interval meets [begin, end)
+    auto chunks = [&](unsigned long long base, unsigned long long lo0, unsigned long long hi0, auto&& f) {
+        for (unsigned long long lo = lo0; lo < hi0; lo += kChunk)
+            if (overlap(base + lo, (hi0 - lo < kChunk) ? hi0 - lo : (unsigned long long)kChunk, begin, end)) f((int)lo);
+    };
+    auto visit = [&](auto&& emit) {   // emit(table, a_field, first subset, rank offset)
         if (last == kHole) return;
         if (FUSED) {
             unsigned long long rb = rb0;
             const int lim = n - m + D;  // largest column selectable at depth D
             for (int a = last + 1; a <= lim; ++a) {
                 const int R = n - 1 - a;
-                const unsigned long long L = binom(d, R, KD);
-                if (R >= min_child_R)
-                    for (unsigned long long lo = 0; lo < L; lo += kChunk)
-                        if (overlap(rb + lo, (L - lo < kChunk) ? L - lo : (unsigned long long)kChunk, begin, end))
-                            emit(a, (int)(lo / kChunk), (int)(rb - rb0));
+                const unsigned long long L = s_b6[R];
+                if (R >= min_child_R) {
+                    // groups j2 = 0, 1, ... with at least kGrandMin columns left; consecutive small
+                    // groups are packed into one item (the child pivot is paid once per item)
+                    unsigned long long off2 = 0, pack_off = 0, pack_n = 0;
+                    int pack_j2 = 0, pack_ng = 0;
+                    auto flush = [&]() {
+                        if (pack_ng && overlap(rb + pack_off, pack_n, begin, end))
+                            emit(1, a | (pack_j2 << 8) | (pack_ng << 16), 0, (int)(rb + pack_off - rb0));
+                        pack_ng = 0;
+                        pack_n = 0;
+                    };
+                    for (int j2 = 0; R - 1 - j2 >= kGrandMin; ++j2) {
+                        const unsigned long long cnt2 = s_b5[R - 1 - j2];
+                        if (cnt2 >= (unsigned long long)kChunk) {
+                            flush();
+                            chunks(rb + off2, 0, cnt2,
+                                   [&](int lo) { emit(1, a | (j2 << 8) | (1 << 16), lo, (int)(rb + off2 - rb0)); });
+                        } else {
+                            if (pack_n + cnt2 > (unsigned long long)kChunk) flush();
+                            if (pack_ng == 0) {
+                                pack_j2 = j2;
+                                pack_off = off2;
+                            }
+                            ++pack_ng;
+                            pack_n += cnt2;
+                        }
+                        off2 += cnt2;
+                    }
+                    flush();
+                    chunks(rb, off2, L, [&](int lo) { emit(0, a, lo, (int)(rb - rb0)); });
+                }
                 rb += L;
             }
         } else {
-            const int R = n - 1 - last;
-            const unsigned long long L = binom(d, R, KD);
-            for (unsigned long long lo = 0; lo < L; lo += kChunk)
-                if (overlap(rb0 + lo, (L - lo < kChunk) ? L - lo : (unsigned long long)kChunk, begin, end))
-                    emit(last, (int)(lo / kChunk), 0);
+            chunks(rb0, 0, s_b6[n - 1 - last], [&](int lo) { emit(0, last, lo, 0); });
         }
     };
-    visit([&](int, int, int) { ++nch; });
-    // inclusive wave scan of nch
-    int incl = nch;
+    int nch[2] = {0, 0};
+    visit([&](int tab, int, int, int) { ++nch[tab]; });
+    int at[2];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+    for (int tab = 0; tab < 2; ++tab) {
+        int incl = nch[tab];   // inclusive wave scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&pd.item_count[tab], total);
+        base = __shfl(base, 63, 64);
+        at[tab] = base + incl - nch[tab];
     }
-    const int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total > 0) base = atomicAdd(pd.item_count, total);
-    base = __shfl(base, 63, 64);
-    int at = base + incl - nch;
-    visit([&](int a, int chunk, int roff) {
-        if (at < pd.item_cap) pd.items[at] = make_int4(rec, a, chunk, roff);
-        ++at;
+    visit([&](int tab, int a, int lo, int roff) {
+        int4* items = tab ? pd.items2 : pd.items;
+        const int cap = tab ? pd.item_cap2 : pd.item_cap;
+        const int k = tab ? at[1]++ : at[0]++;
+        if (k < cap) items[k] = make_int4(rec, a, lo, roff);
     });
 }
 
-// FUSED: work items (record, child, chunk) over the depth m-7 records; the wave pivots on the
-// child column itself, the lanes take the 6 remaining columns.  !FUSED (m = 6): the root record
-// is the depth m-6 node.
-template <bool FUSED>
+// MODE 1: work items of table 0 over the depth m-7 records; the wave pivots on the child column
+//         itself (depth m-6 tableau in LDS), the lanes take the 6 remaining columns.
+// MODE 2: work items of table 1; the wave pivots twice (child, then the group's first column j2:
+//         depth m-5 tableau in LDS) and the lanes take the 5 remaining columns — consecutive
+//         subsets share their first remaining column and with it the whole first elimination
+//         step, which costs a lane a third of its instructions.  A kernel of its own so that the
+//         register allocation of MODE 1's loop is not disturbed (the two loops in one kernel cost
+//         that loop 12 %).
+// MODE 0 (m = 6): the root record is the depth m-6 node.
+template <int MODE>
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, unsigned long long begin,
                    unsigned long long end) {
+    constexpr bool FUSED = MODE != 0;
     constexpr int KD = 6;
     constexpr int MAXCOLS = NMX + KD + 1 + (FUSED ? 1 : 0);  // columns of a record (+ rhs)
     constexpr int CHILDCOLS = NMX + KD + 1;                  // columns of a depth m-6 tableau (+ rhs)
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
     __shared__ __attribute__((aligned(16))) double s_child[FUSED ? LEAF_WAVES : 1][FUSED ? CHILDCOLS * TS : 1];
+    __shared__ __attribute__((aligned(16))) double s_grand[MODE == 2 ? LEAF_WAVES : 1][MODE == 2 ? (NMX + KD) * TS : 1];
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
     __shared__ unsigned long long s_cnt[3];
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
 
     const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
-    const int nitems = min(*pd.item_count, pd.item_cap);        // built by k_enum_make_items
-    int* const cursor = pd.root_cursor;
+    const int4* const items = MODE == 2 ? pd.items2 : pd.items;   // built by k_enum_make_items
+    const int nitems = MODE == 2 ? min(pd.item_count[1], pd.item_cap2) : min(pd.item_count[0], pd.item_cap);
+    int* const cursor = pd.root_cursor + (MODE == 2 ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
-    if (tid < 32) s_off[tid] = pd.comb6[tid];
+    if (tid < 32) s_off[tid] = MODE == 2 ? pd.comb5[tid] : pd.comb6[tid];
     __syncthreads();
     unsigned int cntF = 0, cntI = 0, cntS = 0;
 
@@ -307,7 +366,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     NodeMeta pmB;
     int chunkB = 0, childB = 0, roffB = 0;
     auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
-        const int4 it = pd.items[item];
+        const int4 it = items[item];
         childB = it.y;
         chunkB = it.z;
         roffB = it.w;
@@ -339,15 +398,19 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
         itemC = draw();
         if (itemB < nitems) fetch(itemB);
         if (pm.last_col == kHole) continue;
-        const int last = FUSED ? child : pm.last_col;  // last chosen column of the depth m-6 node
-        const int R = n - 1 - last;                    // selectable columns
+        const int child_col = FUSED ? (child & 0xFF) : pm.last_col;   // last chosen column of the depth m-6 node
+        const int j2_first = (child >> 8) & 0xFF;      // MODE 2: first remaining column of the (first) group
+        const int ngroups = child >> 16;               // MODE 2: groups packed into this item
+        const int last = child_col;
+        const int R = n - 1 - last;                    // selectable columns of the depth m-6 node
         if (R < KD) continue;
-        const unsigned int L = s_binom[R * (KD + 1) + KD];  // C(R, 6) subsets below this node
+        // subsets of this item: [leaf_lo, leaf_hi) inside the node (MODE 0/1) or inside the group (MODE 2)
+        const unsigned int L = s_binom[R * (KD + 1) + KD];   // (MODE 0/1)
         // subset table: all 6-subsets of R columns in lexicographic order, 5 bits per index
         // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
-        const unsigned* comb = pd.comb6 + s_off[R];
-        const unsigned long long rb = pm.rank_base + (unsigned long long)(FUSED ? roff : 0);
-        const unsigned int leaf_lo = (unsigned int)chunk * kChunk;
+        const unsigned* comb = pd.comb6 + s_off[MODE == 2 ? 0 : R];
+        unsigned long long rb = pm.rank_base + (unsigned long long)(FUSED ? roff : 0);
+        const unsigned int leaf_lo = (unsigned int)chunk;
         const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
         double minp0 = pm.minp, maxp0 = pm.maxp;
         unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
@@ -356,7 +419,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             // arithmetic of k_enum_expand (first unused row of largest |w|; l = -(w/piv) as w * (1/piv))
             const int r = lane & (PG - 1), g = lane >> 4;
             const bool row_used = (r >= m) || ((umask >> r) & 1u);
-            const double* pcol = tab + (child - D) * TS;
+            const double* pcol = tab + (child_col - D) * TS;
             const double w = pcol[r];
             double big;
             const int p = __builtin_amdgcn_readfirstlane(pick_pivot_row(w, row_used, lane & ~(PG - 1), big));
@@ -364,7 +427,13 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             maxp0 = fmax(maxp0, big);
             if (!(big > 0.0) || minp0 <= DBL_EPSILON * (double)m * maxp0) {
                 // every subset below this node is singular
-                if (lane == 0) cntS += (unsigned int)overlap(rb + leaf_lo, leaf_hi - leaf_lo, begin, end);
+                unsigned int span = leaf_hi - leaf_lo;
+                if (MODE == 2) {
+                    span = 0;
+                    for (int gi = 0; gi < ngroups; ++gi) span += s_binom[(R - 1 - j2_first - gi) * (KD + 1) + KD - 1];
+                    if (ngroups == 1) span = min(span - leaf_lo, (unsigned int)kChunk);
+                }
+                if (lane == 0) cntS += (unsigned int)overlap(rb + leaf_lo, span, begin, end);
                 continue;
             }
             const double inv = 1.0 / pcol[p];
@@ -383,7 +452,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
                 const int j = g + 4 * q;            // child column j = column child+1+j (j = R: rhs)
                 if (j <= R) {
-                    const double* pc = tab + (child + 1 + j - D) * TS;
+                    const double* pc = tab + (child_col + 1 + j - D) * TS;
                     ctab[j * TS + pos] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
                 }
             }
@@ -392,6 +461,66 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             tab += (last + 1 - D) * TS;              // column q below = column last+1+q
             // (m = 6: the root record, no row used yet — the identity is the permuted order)
         }
+        if constexpr (MODE == 2) {
+            constexpr int K5 = KD - 1;
+            const double minp1 = minp0, maxp1 = maxp0;
+            for (int gi = 0; gi < ngroups; ++gi) {
+            // ---- second pivot, on column j2 of the (row-permuted) child tableau: positions 0..5 are
+            // the unused rows in ascending original order, so "first row of largest |w|" keeps its meaning
+            const int j2 = j2_first + gi;
+            const int R2 = R - 1 - j2;                 // selectable columns of the depth m-5 node
+            const unsigned int L2 = s_binom[R2 * (KD + 1) + K5];
+            const unsigned int lo2 = leaf_lo;          // (0 unless the item is a chunk of one large group)
+            const unsigned int hi2 = (lo2 + kChunk < L2) ? lo2 + kChunk : L2;
+            const unsigned long long rb2 = rb;
+            rb += L2;                                  // next group of a packed item
+            if (overlap(rb2 + lo2, hi2 - lo2, begin, end) == 0ULL) continue;
+            const int r = lane & (PG - 1), g = lane >> 4;
+            const double* pcol = tab + j2 * TS;
+            const double w = pcol[r];
+            double big;
+            const int p2 = __builtin_amdgcn_readfirstlane(pick_pivot_row(w, r >= KD, lane & ~(PG - 1), big));
+            const double minp2 = fmin(minp1, big), maxp2 = fmax(maxp1, big);
+            if (!(big > 0.0) || minp2 <= DBL_EPSILON * (double)m * maxp2) {
+                if (lane == 0) cntS += (unsigned int)overlap(rb2 + lo2, hi2 - lo2, begin, end);
+                continue;
+            }
+            const double inv = 1.0 / pcol[p2];
+            const bool isp = (r == p2);
+            const double lx = isp ? inv : -(w * inv);
+            // rows of the grandchild: the 5 unused ones at 0..4, the new pivot row at 5, the rest stay
+            const int pos = (r < p2) ? r : (r == p2) ? K5 : (r < KD) ? r - 1 : r;
+            double* gtab = s_grand[wave];
+#pragma unroll
+            for (int q = 0; q < (NMX + KD + 3) / 4; ++q) {
+                const int j = g + 4 * q;        // grandchild column j = child column j2+1+j (j = R2: rhs)
+                if (j <= R2) {
+                    const double* pc = tab + (j2 + 1 + j) * TS;
+                    gtab[j * TS + pos] = fma(lx, pc[p2], isp ? -0.0 : pc[r]);
+                }
+            }
+            const unsigned* comb5 = pd.comb5 + s_off[R2];
+            const int U5[K5] = {0, 1, 2, 3, 4};        // unused by leaf_verdict<PERM>
+            for (unsigned int leaf = lo2 + lane; leaf < hi2; leaf += 64) {
+                const unsigned long long rank = rb2 + leaf;
+                if (rank < begin || rank >= end) continue;
+                int c[K5];
+                const unsigned pk = comb5[leaf];
+#pragma unroll
+                for (int t = 0; t < K5; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
+                const int verdict = leaf_verdict<K5, TS, true>(gtab, c, R2, U5, 0u, minp2, maxp2, m);
+                if (verdict == 2) {
+                    ++cntS;
+                } else if (verdict == 1) {
+                    ++cntI;
+                } else {
+                    ++cntF;
+                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                    if (at < pd.list_cap) pd.list[at] = rank;
+                }
+            }
+            }
+        } else {
         const int U[KD] = {0, 1, 2, 3, 4, 5};        // unused by leaf_verdict<PERM>
         for (unsigned int leaf = leaf_lo + lane; leaf < leaf_hi; leaf += 64) {
             const unsigned long long rank = rb + leaf;
@@ -410,6 +539,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
                 if (at < pd.list_cap) pd.list[at] = rank;
             }
+        }
         }
     }
     if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
@@ -490,29 +620,40 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
                           uint64_t bound6, uint64_t begin, uint64_t end) {
     lp_context* ctx = p->ctx;
     PrefixDev& pd = p->prefix;
-    const uint64_t total = lp_host_binom(p->dev.n, p->dev.m);
-    const uint64_t want = bound6 + total / kChunk + 1024;
-    if ((uint64_t)pd.item_cap < want) {
-        if (pd.items) (void)hipFree(pd.items);
-        pd.items = nullptr;
-        pd.item_cap = 0;
-        LP_HIP(ctx, hipMalloc(&pd.items, sizeof(int4) * want));
-        pd.item_cap = (int)std::min<uint64_t>(want, 0x7FFFFFFFULL);
+    const int n = p->dev.n, m = p->dev.m;
+    const uint64_t total = lp_host_binom(n, m);
+    auto ensure = [&](int4*& items, int& cap, uint64_t want) -> int {
+        if ((uint64_t)cap >= want) return LP_OPTIMAL;
+        if (items) (void)hipFree(items);
+        items = nullptr;
+        cap = 0;
+        LP_HIP(ctx, hipMalloc(&items, sizeof(int4) * want));
+        cap = (int)std::min<uint64_t>(want, 0x7FFFFFFFULL);
+        return LP_OPTIMAL;
+    };
+    int rc = ensure(pd.items, pd.item_cap, bound6 + total / kChunk + 1024);
+    if (rc) return rc;
+    if (fused) {
+        // table 1: one item per chunk of a depth m-5 node with >= kGrandMin selectable columns
+        // (their last chosen column is < n - kGrandMin: at most C(n - kGrandMin, m - 5) nodes)
+        rc = ensure(pd.items2, pd.item_cap2, lp_host_binom(n - kGrandMin, m - 5) + total / kChunk + 1024);
+        if (rc) return rc;
     }
-    LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, sizeof(int), ctx->stream));
+    LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, 2 * sizeof(int), ctx->stream));
     // persistent waves (items are dealt dynamically): as many blocks as are resident
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
     if (fused) {
         hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, THIN_TAIL, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<true>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
         hipLaunchKernelGGL(k_enum_thin, (unsigned)lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS),
                            LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<false>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<0>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
     }
     return LP_OPTIMAL;
 }
