@@ -215,6 +215,52 @@ def test_prefix_singular_subtrees(ctx):
     p.free()
 
 
+@pytest.mark.parametrize("m,n", [(8, 24), (9, 22), (7, 23)])
+def test_prefix_singular_pivots_at_every_stage(ctx, m, n):
+    """Duplicate / zero / proportional columns placed so that a singular pivot turns up in the
+    breadth-first levels (holes), in the leaf kernels' in-LDS pivots (child and group), in the
+    lanes' own steps, in the 2x2 block and in the thin kernel — whole ranges and shards."""
+    A, b, c, _ = lpcases.random_lp(100 + n, m, n)   # [A0 | I]: feasible bases exist
+    A[:, 1] = A[:, 0]                 # pruned at depth 2: a hole high in the tree
+    A[:, m - 3] = 3.0 * A[:, m - 5]   # singular around the depth m-7 .. m-5 pivots
+    A[:, n // 2] = 0.0                # zero column in the middle
+    A[:, n - 2] = A[:, n - 5]         # late: the lanes' own steps / the thin kernel's tails
+    A[:, n - 1] = 0.5 * A[:, n - 3]   # and the 2x2 block
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    assert counts[2] > total // 4 and counts[0] > 0
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, _ = p.range(0, total, capi.ENUM_PREFIX)
+    assert (rc, gz, gcounts) == (st, z, counts)
+    assert p.first_within(0, total, z) == o.enum_first_within(A, b, c, True, 0, total, z)
+    cuts = [0, total // 7, total // 3, total // 2 + 11, total - 1000, total]
+    acc = np.zeros(3, dtype=np.int64)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r1, zz, cc, _ = p.range(lo, hi, capi.ENUM_PREFIX)
+        assert (r1, zz, cc) == o.enum_range(A, b, c, True, lo, hi)
+        acc += cc
+    assert acc.tolist() == counts
+    p.free()
+
+
+def test_prefix_all_singular(ctx):
+    """Two equal rows: (nearly) no subset is regular — whole subtrees are cut as soon as a level sees
+    it; the few subsets whose cancellation leaves a pivot above the threshold are classified by
+    the same arithmetic on both sides."""
+    rng = np.random.default_rng(5)
+    m, n = 8, 22
+    A = rng.uniform(size=(m, n))
+    A[5] = A[2]
+    b = rng.uniform(1, 2, size=m)
+    c = rng.uniform(size=n)
+    total = o.binom(n, m)
+    p = ctx.enum_problem(A, b, c, True)
+    rc, gz, gcounts, _ = p.range(0, total, capi.ENUM_PREFIX)
+    ref = o.enum_range(A, b, c, True, 0, total)
+    assert (rc, gz, gcounts) == ref and gcounts[2] > 0.99 * total
+    p.free()
+
+
 def test_prefix_rejects_unsupported_shapes(ctx):
     A, b, c, _ = lpcases.random_lp(1, 3, 7)
     p = ctx.enum_problem(A, b, c, True)
