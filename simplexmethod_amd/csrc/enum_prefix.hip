@@ -153,11 +153,17 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         const double inv = 1.0 / piv;
         const bool isp = (gl == p);
         const double lx = isp ? inv : -(w * inv);
-#pragma unroll 4
-        for (int c = a + 1; c < n; ++c) {
-            const double own = P[(size_t)(c - t) * PG + gl];
-            const double pc = bcast16(own, addr);
-            C[(size_t)(c - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own);
+        // columns a+1 .. n-1, six at a time with all their loads issued before the first use (a
+        // one-column loop waits out a memory round trip per column)
+        for (int c0 = a + 1; c0 < n; c0 += 6) {
+            double own[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) own[u] = (c0 + u < n) ? P[(size_t)(c0 + u - t) * PG + gl] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const double pc = bcast16(own[u], addr);
+                if (c0 + u < n) C[(size_t)(c0 + u - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own[u]);
+            }
         }
         const double pr = bcast16(prhs, addr);
         C[(size_t)(n - t - 1) * PG + gl] = fma(lx, pr, isp ? -0.0 : prhs);
@@ -281,35 +287,15 @@ struct MuDesc {   // 48 bytes
     int pad;
 };
 
-// P[ka] for a dynamic (group-uniform) ka: binary select tree on the bits of ka (depth log2 SP
-// instead of a chain of SP dependent selects).
-#ifndef LP_SEL_TREE
-#define LP_SEL_TREE 0
-#endif
-#ifndef LP_STATIC_ROOTS
-#define LP_STATIC_ROOTS 0
-#endif
+// P[ka] for a dynamic (group-uniform) ka: a chain of SP selects (a binary select tree on the
+// bits of ka was measured slower: more live registers for no shorter critical path).
 template <int SP>
 __device__ __forceinline__ double select_slot(const double (&P)[SP], int ka) {
-#if !LP_SEL_TREE
     double w = 0.0;
 #pragma unroll
     for (int k = 0; k < SP; ++k)
         if (k == ka) w = P[k];
     return w;
-#endif
-    constexpr int N1 = (SP + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
-    double v1[N1], v2[N2], v3[N3], v4[N4];
-#pragma unroll
-    for (int j = 0; j < N1; ++j) v1[j] = ((ka & 1) && 2 * j + 1 < SP) ? P[2 * j + 1 < SP ? 2 * j + 1 : 0] : P[2 * j];
-#pragma unroll
-    for (int j = 0; j < N2; ++j) v2[j] = ((ka & 2) && 2 * j + 1 < N1) ? v1[2 * j + 1 < N1 ? 2 * j + 1 : 0] : v1[2 * j];
-#pragma unroll
-    for (int j = 0; j < N3; ++j) v3[j] = ((ka & 4) && 2 * j + 1 < N2) ? v2[2 * j + 1 < N2 ? 2 * j + 1 : 0] : v2[2 * j];
-#pragma unroll
-    for (int j = 0; j < N4; ++j) v4[j] = ((ka & 8) && 2 * j + 1 < N3) ? v3[2 * j + 1 < N3 ? 2 * j + 1 : 0] : v3[2 * j];
-    static_assert(N4 <= 2, "select_slot handles up to 32 slots");
-    return ((ka & 16) && N4 > 1) ? v4[N4 > 1 ? 1 : 0] : v4[0];
 }
 
 // One Gauss-Jordan pivot on parent slot `ka` (dynamic, uniform in the group): child slot k-1
@@ -405,7 +391,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, Pref
     __shared__ __attribute__((aligned(16))) double s_pool[SWEEP_GROUPS * POOLC * PG];
     __shared__ MuDesc s_desc[SWEEP_GROUPS * MAXMU];
     __shared__ unsigned char s_pairmu[PAIRCAP];
-    __shared__ int s_npairs, s_nmu;
+    __shared__ int s_npairs;
 
     const int m = d.m, n = d.n, D0 = m - 5;
     const int tid = threadIdx.x;
@@ -427,17 +413,13 @@ __global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, Pref
     unsigned long long rb5 = 0, rb4 = 0, rb3 = 0;  // rank base of the NEXT child at each level
     int a5 = 0, a4 = 0, a3 = 0;                    // last child column taken at each level
     bool have5 = false, have4 = false, have3 = false, active = true;
-    int next_root = blockIdx.x * SWEEP_GROUPS + grp;
     unsigned int cntF = 0, cntI = 0, cntS = 0;        // per-lane (pair phase; far below 2^32 each)
     unsigned long long cntSg = 0;                     // per-group (pruned singular subtrees)
     __shared__ unsigned long long s_cnt[3];
     if (tid < 3) s_cnt[tid] = 0ULL;
 
     for (;;) {
-        if (tid == 0) {
-            s_npairs = 0;
-            s_nmu = 0;
-        }
+        if (tid == 0) s_npairs = 0;
         __syncthreads();
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if (pd.dbg) t0 = __builtin_readcyclecounter();
@@ -448,16 +430,11 @@ __global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, Pref
         while (__any(active && !have3)) {
             const bool need = active && !have3;
             if (need && !have5) {
-                // roots are dealt round-robin to the groups of the grid: consecutive records
-                // (similar subtree sizes) go to different groups, and no atomic sits on the path
-#if LP_STATIC_ROOTS
-                const int idx = next_root;
-                next_root += gridDim.x * SWEEP_GROUPS;
-#else
+                // roots are dealt dynamically (a static round-robin assignment was measured slower:
+                // subtree sizes differ too much)
                 int idx = 0;
                 if (gl == 0) idx = atomicAdd(pd.root_cursor, 1);
                 idx = __shfl(idx, 0, PG);
-#endif
                 if (idx >= nroots) {
                     active = false;
                 } else {
