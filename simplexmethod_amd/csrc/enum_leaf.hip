@@ -178,6 +178,7 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
 }
 
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
+constexpr int kItemLanes = 4;  // lanes of k_enum_make_items that share one record
 
 // Work items of the leaf kernels, so that no item is longer than 16 wave passes — a depth m-6 node
 // can hold up to C(22,6) = 74,613 subsets, and a rank-range shard of an 8-GPU run is only a few
@@ -194,7 +195,7 @@ constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
 //     chunk inside the child, rank offset of the child inside the record).
 // !FUSED (m = 6): the one record is the depth m-6 root itself, table 0 only.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd,
+__global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev pd,
                                                          const double* __restrict__ roots,
                                                          int root_level, int root_cap, int min_child_R,
                                                          unsigned long long begin,
@@ -210,7 +211,10 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
     __syncthreads();
     const int n = d.n, m = d.m, D = m - KD - (FUSED ? 1 : 0);
     const int nroots = min(pd.level_counts[root_level], root_cap);
-    const int rec = blockIdx.x * blockDim.x + threadIdx.x;
+    // kItemLanes lanes share a record: lane `sub` takes the children sub, sub + kItemLanes, ... (the
+    // order of the items in the tables does not matter)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rec = FUSED ? gid / kItemLanes : gid, sub = FUSED ? gid % kItemLanes : 0;
     const int lane = threadIdx.x & 63;
     int last = kHole;
     unsigned long long rb0 = 0ULL;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
             for (int a = last + 1; a <= lim; ++a) {
                 const int R = n - 1 - a;
                 const unsigned long long L = s_b6[R];
-                if (R >= min_child_R) {
+                if (R >= min_child_R && (a - last - 1) % kItemLanes == sub) {
                     // groups j2 = 0, 1, ... with at least kGrandMin columns left; consecutive small
                     // groups are packed into one item (the child pivot is paid once per item)
                     unsigned long long off2 = 0, pack_off = 0, pack_n = 0;
@@ -272,6 +276,10 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
     };
     int nch[2] = {0, 0};
     visit([&](int tab, int, int, int) { ++nch[tab]; });
+    // slots: wave scan, then ONE atomic per block and table (a returning atomic on one word costs
+    // ~11 ns chip-wide; at one per wave they were most of this kernel's time)
+    __shared__ int s_wave_total[2][16], s_block_base[2];
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     int at[2];
 #pragma unroll
     for (int tab = 0; tab < 2; ++tab) {
@@ -281,12 +289,23 @@ __global__ __launch_bounds__(256) void k_enum_make_items(EnumDev d, PrefixDev pd
             const int o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (lane == 63 && total > 0) base = atomicAdd(&pd.item_count[tab], total);
-        base = __shfl(base, 63, 64);
-        at[tab] = base + incl - nch[tab];
+        if (lane == 63) s_wave_total[tab][wave] = incl;
+        at[tab] = incl - nch[tab];
     }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int tab = threadIdx.x;
+        int total = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int t = s_wave_total[tab][w];
+            s_wave_total[tab][w] = total;   // exclusive prefix over the waves
+            total += t;
+        }
+        s_block_base[tab] = total ? atomicAdd(&pd.item_count[tab], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tab = 0; tab < 2; ++tab) at[tab] += s_block_base[tab] + s_wave_total[tab][wave];
     visit([&](int tab, int a, int lo, int roff) {
         int4* items = tab ? pd.items2 : pd.items;
         const int cap = tab ? pd.item_cap2 : pd.item_cap;
@@ -564,7 +583,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     const int tid = threadIdx.x;
     if (tid < 3) s_cnt[tid] = 0ULL;
     __syncthreads();
-    const long long gid = (long long)blockIdx.x * LEAF_THREADS + tid;
+    // grid-stride over (record, tail subset) pairs: the grid is sized to the chip, and the three
+    // counters leave a block with three atomics in total (one block per 32 records would put
+    // 190 k atomics on three words for C(32,16): 0.7 ms at ~11 ns each)
+    unsigned int cnt[3] = {0u, 0u, 0u};
+    for (long long gid = (long long)blockIdx.x * LEAF_THREADS + tid; gid < (long long)nrec * 8;
+         gid += (long long)gridDim.x * LEAF_THREADS) {
     const int rec = (int)(gid >> 3), j = (int)(gid & 7);
     int verdict = -1;
     unsigned long long rank = 0ULL;
@@ -600,11 +624,17 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
         const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
         if (at < pd.list_cap) pd.list[at] = rank;
     }
-    // counts: one atomic per wave and verdict
+    cnt[0] += verdict == 0;
+    cnt[1] += verdict == 1;
+    cnt[2] += verdict == 2;
+    }
+    // counts: wave reduction, one LDS atomic per wave and verdict
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
-        const unsigned long long bal = __ballot(verdict == v);
-        if ((tid & 63) == 0 && bal) atomicAdd(&s_cnt[v], (unsigned long long)__popcll(bal));
+        unsigned int c = cnt[v];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_cnt[v], (unsigned long long)c);
     }
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
@@ -644,14 +674,14 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
     if (fused) {
-        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
+        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * kItemLanes, 1024), 1024, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, THIN_TAIL, b, e);
         hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
         hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
-        hipLaunchKernelGGL(k_enum_thin, (unsigned)lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS),
+        hipLaunchKernelGGL(k_enum_thin, (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12),
                            LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
     } else {
-        hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd,
+        hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 1024), 1024, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, b, e);
         hipLaunchKernelGGL(k_enum_leaves<0>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
     }
