@@ -122,16 +122,22 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         }
         // ---- pricing, :152-174, on the LDS-resident reduced-cost row
         LP_STAMP(0);
-        int e;
-        {
+        // (one wave scans the whole row — 16 entries per lane at n = 1024 — and publishes the result:
+        // two wave reductions and one barrier instead of a two-stage block reduction with two)
+        if (tid < 64) {
             double best;
-            if (d.maximize)
-                e = lpdev::block_chain_select<true>(s.d, s.nb, n, eps, best, s.sc);
-            else
-                e = lpdev::block_chain_select<false>(s.d, s.nb, n, eps, best, s.sc);
+            auto load = [&](int j, bool& ok) {
+                ok = s.nb[j] != 0;  // complement(), :97-108
+                return s.d[j];
+            };
+            int e0 = d.maximize ? lpdev::wave_chain_select<true>(n, eps, best, load)
+                                : lpdev::wave_chain_select<false>(n, eps, best, load);
             const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
-            if (optimal) e = -1;
+            if (optimal) e0 = -1;
+            if (tid == 0) s.sc->sel = e0;
         }
+        __syncthreads();
+        const int e = s.sc->sel;
         LP_STAMP(1);
         if (e < 0) {
             status = LP_OPTIMAL;
@@ -159,9 +165,18 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         }
         LP_STAMP(2);
         // ---- ratio test, :181-194
-        double theta;
         // ineligible rows hold +inf, which the < scan never takes
-        const int r = lpdev::block_chain_select<false>(s.ratio, nullptr, m, eps, theta, s.sc);
+        if (tid < 64) {
+            double theta;
+            auto load = [&](int i, bool& ok) {
+                ok = true;
+                return s.ratio[i];
+            };
+            const int r0 = lpdev::wave_chain_select<false>(m, eps, theta, load);
+            if (tid == 0) s.sc->sel = r0;
+        }
+        __syncthreads();
+        const int r = s.sc->sel;
         LP_STAMP(3);
         if (r < 0) {
             status = LP_UNBOUNDED;
