@@ -115,34 +115,37 @@ __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
     best = sentinel;
     int sel = -1;
     for (int base = 0; base < len; base += TILE) {
+        // (only one wave runs here, so what counts is the length of the dependent instruction
+        // chains: extremes are balanced v_max/v_min trees, indices are found afterwards)
         double val[K];
-        double lext = sentinel;  // this lane's extreme value and its first index
-        int lidx = INT_MAX;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int j = base + k * 64 + lane;
             // unconditional (clamped) load so that all K loads are in flight together
             bool ok = false;
             double v = load(j < len ? j : len - 1, ok);
-            v = (ok && j < len) ? v : sentinel;
-            val[k] = v;
-            if (WANT_MAX ? (v > lext) : (v < lext)) {
-                lext = v;
-                lidx = j;
-            }
+            val[k] = (ok && j < len) ? v : sentinel;
         }
+        auto ext = [](double a, double b) { return WANT_MAX ? fmax(a, b) : fmin(a, b); };
+        auto tree = [&](const double (&x)[K]) {
+            static_assert(K == 16, "tree below is written for 16 entries");
+            const double a0 = ext(x[0], x[1]), a1 = ext(x[2], x[3]), a2 = ext(x[4], x[5]), a3 = ext(x[6], x[7]);
+            const double a4 = ext(x[8], x[9]), a5 = ext(x[10], x[11]), a6 = ext(x[12], x[13]), a7 = ext(x[14], x[15]);
+            return ext(ext(ext(a0, a1), ext(a2, a3)), ext(ext(a4, a5), ext(a6, a7)));
+        };
+        const double lext = tree(val);  // this lane's extreme value (NaN entries never win: fmax/fmin drop them)
         // ---- fast path
         const double M = wave_ext_f64<WANT_MAX>(lext);
         const double thr_in = WANT_MAX ? best + eps : best - eps;
         if (!(WANT_MAX ? (M > thr_in) : (M < thr_in))) continue;  // nothing here is accepted
-        const int jM = wave_min_i32((lext == M) ? lidx : INT_MAX);
-        double lp = sentinel;  // extreme of this lane's entries before jM
+        int lidx = INT_MAX;             // first index at which this lane holds M
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int j = base + k * 64 + lane;
-            if (j < jM && (WANT_MAX ? (val[k] > lp) : (val[k] < lp))) lp = val[k];
-        }
-        double P = wave_ext_f64<WANT_MAX>(lp);
+        for (int k = K - 1; k >= 0; --k) lidx = (val[k] == M) ? base + k * 64 + lane : lidx;
+        const int jM = wave_min_i32(lidx);
+        double before[K];               // entries before jM
+#pragma unroll
+        for (int k = 0; k < K; ++k) before[k] = (base + k * 64 + lane < jM) ? val[k] : sentinel;
+        double P = wave_ext_f64<WANT_MAX>(tree(before));
         if (WANT_MAX ? (best > P) : (best < P)) P = best;
         if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
             best = M;
