@@ -9,15 +9,20 @@
 // partially eliminated tableau restricted to the columns still selectable, [W[:, c > last] | rhs]
 // (16 rows x <= n-t+1 columns), the used-row mask and min/max |pivot|.
 //
-//   phase 1  k_enum_expand   levels 0 .. D0 = m-5 breadth-first through HBM: one 16-lane
-//            group (lane = row) per parent streams its columns from HBM, pivots on each
-//            child column and writes the child record.  Cheap (few nodes), bandwidth-shaped.
-//   phase 2  k_enum_sweep    one group per depth-D0 node: three more levels (m-5, m-4, m-3)
-//            live in REGISTERS (lane = row, column slot = static register index; the pivot
-//            column is picked with a select chain, the pivot row is broadcast lane->group).
-//            Depth m-2 nodes ("mu": two unused rows left) are written to LDS, and the last
-//            two columns are then enumerated by ALL lanes of the workgroup, one lane per
-//            subset: 2x2 block solve, back-substitution over the used rows, feasibility.
+//   phase 1  k_enum_expand / k_enum_expand_narrow (this file): levels 0 .. D0 breadth-first
+//            through HBM (D0 = m-7 for the default second phase).  One wave per parent, its
+//            four 16-lane groups (lane = row) pivot four children at a time and write the child
+//            records; a block of 64 parents takes all its children's slots with one atomic.
+//            Narrow levels: one wave per (parent, child).  Bandwidth-shaped (7 GB for C(32,16)).
+//   phase 2  default: the leaf kernels of enum_leaf.hip (one lane per subset from the depth
+//            m-7 records, with one or two more pivots done by the wave in LDS).
+//            LP_ENUM_SWEEP=1: k_enum_sweep (this file), an independent cooperative variant kept
+//            for cross-checking — one group per depth m-5 node, three more levels (m-5, m-4,
+//            m-3) in REGISTERS (lane = row, column slot = static register index; the pivot
+//            column is picked with a select chain, the pivot row is broadcast lane->group);
+//            depth m-2 nodes ("mu": two unused rows left) are written to LDS, and the last two
+//            columns are enumerated by ALL lanes of the workgroup, one lane per subset.  It
+//            shares more arithmetic but is latency-bound: > 10x slower than the leaf kernels.
 //   Feasible subsets are rare; their ranks are appended to a list and their objectives are
 //   evaluated afterwards by the direct solver (enum_direct.hip: k_enum_eval_list), which
 //   also serves pass 2 (tie rule) without a second enumeration.
