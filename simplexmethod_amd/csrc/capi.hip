@@ -640,6 +640,7 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     double score = -INFINITY;
     uint64_t counts[3] = {0, 0, 0};
     p->list_valid = false;
+    p->spec_valid = false;
     if (algo == LP_ENUM_ALGO_AUTO)  // the shared-prefix path pays off once the tree is deep and wide
         algo = (lp_enum_prefix_supported(p) && rank_end - rank_begin >= (1ULL << 20)) ? LP_ENUM_ALGO_PREFIX
                                                                                         : LP_ENUM_ALGO_DIRECT;
@@ -672,8 +673,13 @@ int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_
     int rc = check_range(p, rank_begin, rank_end);
     if (rc) return rc;
     const double star = p->dev.maximize ? zstar : -zstar;
-    if (p->list_valid && p->list_begin == rank_begin && p->list_end == rank_end)
+    if (p->list_valid && p->list_begin == rank_begin && p->list_end == rank_end) {
+        if (p->spec_valid && star == p->spec_star && tol == p->spec_tol) {
+            *rank_out = p->spec_first;  // already applied on the device by the range pass
+            return LP_OPTIMAL;
+        }
         return lp_enum_list_first(p, star, tol, rank_out);  // every feasible subset is listed
+    }
     return lp_enum_direct_first(p, rank_begin, rank_end, star, tol, rank_out);
 }
 

@@ -311,7 +311,12 @@ __global__ __launch_bounds__(64) void k_enum_vertex(EnumDev d, unsigned long lon
 // Objectives of listed ranks (the shared-prefix path's feasible subsets): one group per entry.
 template <int G>
 __global__ __launch_bounds__(256) void k_enum_eval_list(EnumDev d, const unsigned long long* list,
-                                                        unsigned long long count, double* scores) {
+                                                        unsigned long long count,
+                                                        const unsigned long long* count_ptr,
+                                                        unsigned long long cap, double* scores) {
+    // count_ptr != null: the list was filled by kernels queued just before this one and its length
+    // still lives on the device (an over-full list is reported by the host afterwards)
+    if (count_ptr) count = *count_ptr < cap ? *count_ptr : cap;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sA = smem;
     double* sb = sA + d.m * d.lda;
@@ -337,7 +342,14 @@ __global__ __launch_bounds__(256) void k_enum_eval_list(EnumDev d, const unsigne
 }
 
 __global__ void k_enum_list_first(EnumDev d, const unsigned long long* list, unsigned long long count,
+                                  const unsigned long long* count_ptr, unsigned long long cap,
                                   const double* scores, double star, double tol) {
+    // count_ptr != null: queued behind k_enum_eval_list — list length and the best score (the
+    // reference value of the tie rule) are read on the device
+    if (count_ptr) {
+        count = *count_ptr < cap ? *count_ptr : cap;
+        star = lp_key_f64(d.result->best_key);
+    }
     unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     unsigned long long first = ~0ULL;
@@ -489,13 +501,33 @@ int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best) {
     const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(count, 16), (uint64_t)ctx->num_cus * 8);
     if (d.m <= 16)
         hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, p->prefix.list,
-                           (unsigned long long)count, p->prefix.scores);
+                           (unsigned long long)count, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores);
     else
         hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, p->prefix.list,
-                           (unsigned long long)count, p->prefix.scores);
+                           (unsigned long long)count, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores);
     int rc = fetch_result(p);
     if (rc) return rc;
     *score_best = lp_key_f64(p->h_result->best_key);
+    return LP_OPTIMAL;
+}
+
+// Queues, behind the kernels that fill the feasible list, its evaluation and the tie rule against
+// the list's own best score (tolerance tol) — no host round trip: the caller synchronises once and
+// finds best_key and first_rank in the result block.
+int lp_enum_queue_list_tail(lp_enum_problem* p, double tol) {
+    lp_context* ctx = p->ctx;
+    const EnumDev& d = p->dev;
+    const PrefixDev& pd = p->prefix;
+    const size_t shm = enum_smem_bytes(d);
+    const unsigned grid = (unsigned)ctx->num_cus * 2;
+    if (d.m <= 16)
+        hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,
+                           (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores);
+    else
+        hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,
+                           (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores);
+    hipLaunchKernelGGL(k_enum_list_first, 64, 256, 0, ctx->stream, d, pd.list, 0ULL,
+                       (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores, 0.0, tol);
     return LP_OPTIMAL;
 }
 
@@ -507,7 +539,8 @@ int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64
     if (rc) return rc;
     const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(p->list_n, 256), 1024);
     hipLaunchKernelGGL(k_enum_list_first, grid, 256, 0, ctx->stream, p->dev, p->prefix.list,
-                       (unsigned long long)p->list_n, p->prefix.scores, score_star, tol);
+                       (unsigned long long)p->list_n, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores,
+                       score_star, tol);
     rc = fetch_result(p);
     if (rc) return rc;
     *rank_out = p->h_result->first_rank;

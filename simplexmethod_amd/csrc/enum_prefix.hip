@@ -801,6 +801,11 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         ++launches;
     }
     LP_HIP(ctx, hipMemcpyAsync(p->h_level_counts, pd.level_counts, sizeof(int) * 32, hipMemcpyDeviceToHost, s));
+    // objectives of the (few) feasible subsets by the direct solver, and the tie rule against this
+    // range's own best score (what a sharded run asks next): queued behind the leaf kernels
+    constexpr double kSpecTol = 1e-9;   // Solver::EPS, the tolerance dist.py / EnumerationSolver use
+    p->spec_valid = false;
+    if (use_leaf) lp_enum_queue_list_tail(p, kSpecTol);
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -818,10 +823,15 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     if (*p->h_overflow != 0 || *p->h_list_count > pd.list_cap) return LP_ITER_LIMIT;  // fall back
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    // ---- objectives of the (few) feasible subsets, by the direct solver
     const uint64_t nfeas = *p->h_list_count;
     double best = -INFINITY;
-    if (nfeas) {
+    if (use_leaf) {
+        if (nfeas) best = lp_key_f64(p->h_result->best_key);
+        p->spec_valid = true;
+        p->spec_star = best;
+        p->spec_tol = kSpecTol;
+        p->spec_first = nfeas ? p->h_result->first_rank : ~0ULL;
+    } else if (nfeas) {
         int rc = lp_enum_eval_list(p, nfeas, &best);
         if (rc) return rc;
     }

@@ -101,6 +101,10 @@ struct lp_enum_problem {
     bool list_valid = false;                   // the feasible list of the last prefix pass 1 is usable
     uint64_t list_begin = 0, list_end = 0, list_n = 0;
     int last_algo = 0;
+    // tie rule already applied on the device against the range's own best score (prefix path)
+    bool spec_valid = false;
+    double spec_star = 0.0, spec_tol = 0.0;
+    uint64_t spec_first = ~0ULL;
 };
 
 // enum_direct.hip
@@ -114,6 +118,8 @@ int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* su
 int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 // smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
+// evaluation + tie rule against the list's own best, queued without a host round trip
+int lp_enum_queue_list_tail(lp_enum_problem* p, double tol);
 
 // enum_leaf.hip: one lane per subset below the records of the last breadth-first level
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
