@@ -669,7 +669,6 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         rc = ensure(pd.items2, pd.item_cap2, lp_host_binom(n - kGrandMin, m - 5) + total / kChunk + 1024);
         if (rc) return rc;
     }
-    LP_HIP(ctx, hipMemsetAsync(pd.item_count, 0, 2 * sizeof(int), ctx->stream));
     // persistent waves (items are dealt dynamically): as many blocks as are resident
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
