@@ -4,17 +4,22 @@
 // tableau [W[:, c > last] | rhs] after the first m-7 Gauss-Jordan steps, shared by every subset
 // with that prefix.
 //
-// k_enum_leaves (the regular kernel, > 90 % of the subsets).  A wave owns one work item (record,
-// child column, chunk of subsets) at a time: it copies the record to its private LDS slice,
-// performs the pivot on the child column cooperatively (16 rows x 4 columns per step; the depth
-// m-6 tableau never travels through HBM), and each of its 64 lanes then finishes one subset on
-// its own: it picks the remaining 6 columns (table of all 6-subsets in lexicographic order),
-// replays the last four Gauss-Jordan steps and the 2x2 block exactly as oracle/lp_oracle.c:
-// orc_enum_subset orders them, and tests feasibility.  No cross-lane traffic, no barriers, no
-// divergence beyond the leaf loop's tail: the ~900 instructions per subset are ordinary
-// lane-parallel fp64 work, which is what this chip has in abundance (the cooperative sweep of
-// enum_prefix.hip shares two more levels but is bound by the latency of its broadcasts, pivot
-// searches and workgroup barriers).
+// k_enum_leaves<1> (a third of the subsets).  A wave owns one work item (record, child column,
+// chunk of subsets) at a time: it copies the record to its private LDS slice, performs the pivot
+// on the child column cooperatively (16 rows x 4 columns per step; the depth m-6 tableau never
+// travels through HBM; its rows are written permuted, unused rows first), and each of its 64
+// lanes then finishes one subset on its own: it picks the remaining 6 columns (table of all
+// 6-subsets in lexicographic order), replays the last four Gauss-Jordan steps and the 2x2 block
+// exactly as oracle/lp_oracle.c: orc_enum_subset orders them, and tests feasibility.  No
+// cross-lane traffic, no barriers, no divergence beyond the leaf loop's tail: the ~800
+// instructions per subset are ordinary lane-parallel fp64 work, which is what this chip has in
+// abundance (the cooperative sweep of enum_prefix.hip shares two more levels but is bound by the
+// latency of its broadcasts, pivot searches and workgroup barriers).
+//
+// k_enum_leaves<2> (two thirds of the subsets).  The subsets below a child are grouped by their
+// first remaining column; a group that leaves >= kGrandMin selectable columns gets a second
+// in-LDS pivot and its lanes take 5 columns each (items of table 1).  k_enum_leaves<1> finishes
+// what is left of each child (items of table 0).
 //
 // k_enum_thin (the tails).  A depth m-6 node with fewer than 8 selectable columns holds at most
 // C(7,6) = 7 subsets: as a work item it would cost a pivot and a wave pass for a handful of
