@@ -287,3 +287,46 @@ def test_prefix_sweep_variant_agrees(ctx, monkeypatch):
         assert leaf == sweep == (st, z, counts)
         assert kleaf == ksweep == o.enum_first_within(A, b, c, True, 0, total, z)
         p.free()
+
+
+# ---- BASELINE.json's full sizes: size-independent properties -----------------------------------
+
+@pytest.mark.parametrize("m,n", [(14, 28), (16, 32)])   # configs[2], configs[3]
+def test_full_size_properties(ctx, m, n):
+    """C(28,14) = 40,116,600 and C(32,16) = 601,080,390 subsets are too many for the oracle, so:
+    the three counts add up to C(n,m); the optimum is the simplex optimum (a different algorithm
+    on the same GPU); uneven shards compose to the whole (counts add, best = max, tie rule = min);
+    the direct kernel agrees with the shared-prefix kernels on a 20 M window; the oracle agrees on
+    a 200 k window around the optimum."""
+    A, b, c, basis = lpcases.random_lp(0, m, n)
+    p = ctx.enum_problem(A, b, c, True)
+    total = p.total
+    assert total == o.binom(n, m)
+    rc, z, counts, _ = p.range(0, total)
+    assert rc == 0 and sum(counts) == total and counts[0] > 0
+    k = p.first_within(0, total, z)
+    v = p.vertex(k, n - m)
+    assert v["obj"] == z
+    s = ctx.simplex_solve(A, b, c, basis, True, n - m)
+    assert s["status"] == 0 and abs(s["obj"] - z) <= 1e-10 * abs(z)
+    np.testing.assert_allclose(v["x"], s["x"], rtol=0, atol=1e-9)
+    # uneven shards
+    cuts = [0, total // 11, total // 3 + 7, total // 2, total - total // 5, total - 12345, total]
+    acc, bests, firsts = np.zeros(3, dtype=np.int64), [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r1, zz, cc, _ = p.range(lo, hi)
+        acc += cc
+        bests.append(zz if r1 == 0 else -np.inf)
+        firsts.append(p.first_within(lo, hi, z) if r1 == 0 and zz >= z - 1e-9 else 2 ** 64 - 1)
+    assert acc.tolist() == counts and max(bests) == z and min(firsts) == k
+    # direct kernel on a window
+    lo = total // 2
+    hi = min(total, lo + 20_000_000)
+    assert p.range(lo, hi, capi.ENUM_DIRECT)[:3] == p.range(lo, hi, capi.ENUM_PREFIX)[:3]
+    # the oracle on a window around the optimum
+    lo = max(0, k - 100_000)
+    hi = min(total, k + 100_000)
+    st, oz, ocounts = o.enum_range(A, b, c, True, lo, hi)
+    r1, gz, gcounts, _ = p.range(lo, hi)
+    assert (r1, gz, gcounts) == (st, oz, ocounts) and gz == z
+    p.free()
