@@ -71,6 +71,7 @@ SIGNATURES = {
     "lp_batched_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip]),
     "lp_batched_free": (None, [_vp]),
     "lp_binom": (C.c_uint64, [C.c_int, C.c_int]),
+    "lp_enum_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _u64p, _u64p]),
     "lp_enum_solve": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _ip,
                                 _u64p, _dp, _u64p]),
     "lp_enum_upload": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.POINTER(_vp)]),

@@ -479,6 +479,45 @@ int lp_bench_rankj_update(lp_simplex_problem* p, int iters, float* ms_per_launch
 
 uint64_t lp_binom(int n, int k) { return lp_host_binom(n, k); }
 
+// Cost-balanced cut of the rank space (same rule as simplexmethod_amd/dist.py:
+// balanced_shard_bounds): cost(x) = x + kShardRecordCost * (depth m-7 tree nodes before subset x).
+static const uint64_t kShardRecordCost = 190;
+int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_out, uint64_t* end_out) {
+    if (!begin_out || !end_out || shards <= 0 || shard < 0 || shard >= shards) return LP_BAD_ARG;
+    if (m <= 0 || n < m || n > kEnumMaxN || m > kEnumMaxM) return LP_BAD_ARG;
+    const uint64_t total = lp_host_binom(n, m);
+    if (total == 0) return LP_BAD_ARG;
+    const int d0 = m - 7;
+    // (the cost model is the shared-prefix path's; shapes it does not take — m > 16, n - m > 16 or
+    // < 2, small trees — run the direct kernel, whose cost per subset is uniform)
+    const bool prefix_shape = m >= 7 && m <= 16 && n - m >= 2 && n - m <= 16;
+    if (shards == 1 || !prefix_shape || total < (1ULL << 20)) {
+        // (dist.py uses total * k // world here; same partition property, sizes differ by <= 1)
+        *begin_out = (uint64_t)((unsigned __int128)total * (unsigned)shard / (unsigned)shards);
+        *end_out = (uint64_t)((unsigned __int128)total * (unsigned)(shard + 1) / (unsigned)shards);
+        return LP_OPTIMAL;
+    }
+    auto cost = [&](uint64_t x) -> unsigned __int128 {
+        if (x >= total) return (unsigned __int128)total + (unsigned __int128)kShardRecordCost * lp_host_binom(n - 7, d0);
+        return (unsigned __int128)x + (unsigned __int128)kShardRecordCost * lp_host_prefix_rank(n, m, x, d0);
+    };
+    const unsigned __int128 full = cost(total);
+    auto cut = [&](int k) -> uint64_t {
+        if (k <= 0) return 0;
+        if (k >= shards) return total;
+        const unsigned __int128 target = full * (unsigned)k / (unsigned)shards;
+        uint64_t lo = 0, hi = total;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (cost(mid) < target) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    *begin_out = cut(shard);
+    *end_out = cut(shard + 1);
+    return LP_OPTIMAL;
+}
+
 void lp_enum_free(lp_enum_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);

@@ -691,7 +691,7 @@ static size_t host_rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) +
 // Number of depth-t tree nodes whose subtree meets the rank range [begin, end): the length-t
 // prefixes of the subsets begin .. end-1 are consecutive in the lexicographic order of the
 // t-subsets of {0 .. n-m+t-1}, so the count is the difference of two prefix ranks, plus one.
-static uint64_t host_prefix_rank(int n, int m, uint64_t rank, int t) {
+uint64_t lp_host_prefix_rank(int n, int m, uint64_t rank, int t) {
     // unrank the first t elements of the rank-th m-subset, accumulating their rank among t-subsets
     uint64_t pr = 0;
     int a = 0;
@@ -709,7 +709,7 @@ static uint64_t host_prefix_rank(int n, int m, uint64_t rank, int t) {
 }
 static uint64_t host_level_nodes(int n, int m, uint64_t begin, uint64_t end, int t) {
     if (end <= begin) return 0;
-    return host_prefix_rank(n, m, end - 1, t) - host_prefix_rank(n, m, begin, t) + 1;
+    return lp_host_prefix_rank(n, m, end - 1, t) - lp_host_prefix_rank(n, m, begin, t) + 1;
 }
 
 bool lp_enum_prefix_supported(const lp_enum_problem* p) {

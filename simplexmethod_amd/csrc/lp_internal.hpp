@@ -45,3 +45,6 @@ static inline T lp_ceil_div(T a, T b) {
 
 // Host-side combinatorics shared by the enumeration paths (exact u64; 0 = overflow).
 uint64_t lp_host_binom(int n, int k);
+// rank, among the t-subsets of {0 .. n-m+t-1}, of the first t elements of the rank-th m-subset of
+// {0 .. n-1} (enum_prefix.hip)
+uint64_t lp_host_prefix_rank(int n, int m, uint64_t rank, int t);

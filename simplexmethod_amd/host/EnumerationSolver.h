@@ -32,7 +32,8 @@ public:
     // Throws std::runtime_error("No feasible basis") when no basis is feasible.
     lpla::VectorXd solve() { return solve_ex().x; }
 
-    // n_gpus > 1: the rank space is cut into n_gpus contiguous shards, one host thread and one
+    // n_gpus > 1: the rank space is cut into n_gpus contiguous shards of equal estimated cost
+    // (lp_enum_shard_bounds), one host thread and one
     // HIP device per shard; the incumbent is reduced on the host (a single process needs no
     // RCCL — the one-process-per-GPU form over RCCL is simplexmethod_amd/dist.py).
     Result solve_ex(int n_gpus = 1, bool throw_on_failure = true) {
@@ -68,10 +69,8 @@ public:
         std::vector<Shard> sh((size_t)n_gpus);
         for (int g = 0; g < n_gpus; ++g) {
             sh[(size_t)g].ctx = lpgpu::context(_device + g);
-            sh[(size_t)g].lo = total / (uint64_t)n_gpus * (uint64_t)g +
-                               std::min<uint64_t>((uint64_t)g, total % (uint64_t)n_gpus);
-            sh[(size_t)g].hi = total / (uint64_t)n_gpus * (uint64_t)(g + 1) +
-                               std::min<uint64_t>((uint64_t)(g + 1), total % (uint64_t)n_gpus);
+            if (lp_enum_shard_bounds(n, m, g, n_gpus, &sh[(size_t)g].lo, &sh[(size_t)g].hi) != LP_OPTIMAL)
+                throw std::invalid_argument("lp_enum_shard_bounds: bad problem shape");
         }
         auto pass1 = [&](int g) {
             Shard& s = sh[(size_t)g];

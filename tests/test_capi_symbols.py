@@ -71,3 +71,20 @@ def test_generator_matches_oracle_generator():
         b = o.gen_lp(seed, m, n)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_shard_bounds_match_the_python_driver():
+    """lp_enum_shard_bounds (used by the C++ EnumerationSolver's multi-GPU mode) cuts the rank space
+    exactly where simplexmethod_amd.dist.balanced_shard_bounds (used by bench.py) does."""
+    import ctypes as C
+    from simplexmethod_amd import capi, dist as lpdist
+    lib = capi.load()
+    for n, m in [(32, 16), (28, 14), (24, 8), (20, 10), (12, 5), (40, 9)]:
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lo, hi = C.c_uint64(0), C.c_uint64(0)
+                assert lib.lp_enum_shard_bounds(n, m, r, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == lpdist.balanced_shard_bounds(n, m, r, world), (n, m, r, world)
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    assert lib.lp_enum_shard_bounds(32, 16, 8, 8, C.byref(lo), C.byref(hi)) == capi.BAD_ARG
+    assert lib.lp_enum_shard_bounds(10, 12, 0, 2, C.byref(lo), C.byref(hi)) == capi.BAD_ARG
