@@ -213,14 +213,22 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
     // computeBFS (SimplexSolover.h:423): nothing to do for the slack identity basis with
     // zero basic costs (Symmetrical::ToCanonical, Symmetrical.cpp:169-188); otherwise m
     // Gauss-Jordan pivots on the device.
-    bool identity = true;
+    bool identity = true, zero_costs = true;
     for (int t = 0; t < m && identity; ++t) {
-        if (c[basis_in[t]] != 0.0) identity = false;
+        if (c[basis_in[t]] != 0.0) zero_costs = false;
         for (int i = 0; i < m && identity; ++i)
             if (A[(size_t)basis_in[t] * m + i] != ((i == t) ? 1.0 : 0.0)) identity = false;
     }
     p->init_status = LP_OPTIMAL;
-    if (!identity) {
+    if (identity && !zero_costs) {
+        // unit-vector basis with costs (the artificial basis of a phase-I problem): the crash pivots
+        // only touch the reduced-cost row — one pass instead of m rank-1 updates
+        rc = lp_simplex_price_out_identity(p);
+        if (rc) {
+            lp_simplex_free(p);
+            return rc;
+        }
+    } else if (!identity) {
         rc = lp_simplex_crash(p);
         if (rc < 0) {
             lp_simplex_free(p);

@@ -285,6 +285,37 @@ __global__ __launch_bounds__(1024) void k_force_select(SimplexDev d, int row, in
     }
 }
 
+// computeBFS for a basis whose columns are the unit vectors e_t in order but whose costs are not
+// zero (the artificial basis of a phase-I problem): the m crash pivots would have pivot element 1
+// and multipliers 0 on every constraint row, so all they do is eliminate the basic costs from the
+// reduced-cost row, d_j <- fma(-c_N(t), T[t][j], d_j) for t = 0 .. m-1 in order, and set
+// d_N(t) = 0.  One thread per column replays exactly that chain (same values as
+// oracle/lp_oracle.c's crash loop; signs of zero entries of the constraint rows aside).
+__global__ __launch_bounds__(256) void k_price_out_identity(SimplexDev d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > d.n) return;
+    const int m = d.m, ld = d.ld;
+    const double* crow = d.T + (size_t)m * ld;   // still the original costs c
+    double dj = crow[j];
+    int own = -1;   // basis position whose column this is
+    for (int t = 0; t < m; ++t) {
+        const int e = d.basis[t];
+        const double l = -crow[e] / 1.0;
+        dj = (own >= 0) ? dj : fma(l, d.T[(size_t)t * ld + j], dj);
+        if (e == j) {
+            dj = 0.0;
+            own = t;
+        }
+    }
+    // other threads still need the original costs of the basic columns: the result goes to scratch
+    // (prow, ld doubles) and is copied back by k_price_out_commit
+    d.prow[j] = dj;
+}
+__global__ __launch_bounds__(256) void k_price_out_commit(SimplexDev d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j <= d.n) d.T[(size_t)d.m * d.ld + j] = d.prow[j];
+}
+
 // Singularity verdict after the m crash pivots (min|piv| <= eps_mach*m*max|piv|, the
 // FullPivLU::isInvertible threshold the reference relies on at :124-126) and the
 // row permutation to basis-position order: dst row t = src row rowpos[t].
@@ -349,6 +380,16 @@ int lp_simplex_force(lp_simplex_problem* p, int row, int col) {
 void lp_simplex_launch_update(lp_simplex_problem* p) {
     hipLaunchKernelGGL(k_simplex_update, update_grid(p->dev), dim3(UPD_TX, UPD_TY), 0,
                        p->ctx->stream, p->dev);
+}
+
+int lp_simplex_price_out_identity(lp_simplex_problem* p) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    hipLaunchKernelGGL(k_price_out_identity, lp_ceil_div(d.n + 1, 256), 256, 0, ctx->stream, d);
+    hipLaunchKernelGGL(k_price_out_commit, lp_ceil_div(d.n + 1, 256), 256, 0, ctx->stream, d);
+    LP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LP_HIP(ctx, hipGetLastError());
+    return LP_OPTIMAL;
 }
 
 int lp_simplex_crash(lp_simplex_problem* p) {

@@ -69,6 +69,7 @@ struct lp_simplex_problem {
 // simplex_launch.hip
 void lp_simplex_launch_update(lp_simplex_problem* p);
 int lp_simplex_crash(lp_simplex_problem* p);
+int lp_simplex_price_out_identity(lp_simplex_problem* p);  // unit-vector basis with non-zero costs
 int lp_simplex_force(lp_simplex_problem* p, int row, int col);  // host-chosen pivot on the current tableau
 int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
