@@ -59,14 +59,45 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
                                             unsigned used, double minp0, double maxp0, int m) {
     // ---- phase 1: unused rows x chosen columns
     double E[KD][KD], H[KD];
+    // PERM (tableau in LDS): step 0's pivot row is chosen BEFORE the rows are loaded — the entries
+    // are still the tableau's own, so instead of loading rows 0..KD-1 and rotating the chosen one
+    // to the front (2 x (KD-1) selects per element: the largest single cost of a subset), column
+    // c[0] is read first, and the rows then come from LDS already in their rotated order: position
+    // 0 = row p, positions 1.. = the other rows ascending.  (Not for the thin kernel's records in
+    // HBM: a second dependent round trip costs more there than the selects.)
+    int p0 = 0;
+    double big0 = -1.0;
+    if constexpr (PERM) {
+        double col0[KD];
+        const double* cz = tab + c[0] * STRIDE;
 #pragma unroll
-    for (int t = 0; t < KD; ++t) {
-        const double* col = tab + c[t] * STRIDE;
+        for (int r = 0; r < KD; ++r) col0[r] = cz[r];
 #pragma unroll
-        for (int r = 0; r < KD; ++r) E[r][t] = col[PERM ? r : U[r]];
+        for (int r = 0; r < KD; ++r) big0 = fmax(big0, fabs(col0[r]));
+#pragma unroll
+        for (int r = KD - 1; r >= 0; --r) p0 = (fabs(col0[r]) == big0) ? r : p0;   // descending: the first wins
+        int row[KD];
+        row[0] = p0;
+#pragma unroll
+        for (int i = 1; i < KD; ++i) row[i] = (i - 1 < p0) ? i - 1 : i;
+#pragma unroll
+        for (int t = 0; t < KD; ++t) {
+            const double* col = tab + c[t] * STRIDE;
+#pragma unroll
+            for (int r = 0; r < KD; ++r) E[r][t] = col[row[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + row[r]];
+    } else {
+#pragma unroll
+        for (int t = 0; t < KD; ++t) {
+            const double* col = tab + c[t] * STRIDE;
+#pragma unroll
+            for (int r = 0; r < KD; ++r) E[r][t] = col[U[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + U[r]];
     }
-#pragma unroll
-    for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + (PERM ? r : U[r])];
     // Invariant: before step t, rows t..KD-1 of E are the rows not yet used, in ascending
     // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
     // are the pivot rows of steps 0..t-1.  The chosen row p is ROTATED into position t
@@ -79,15 +110,20 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     for (int t = 0; t < KD - 2; ++t) {
         // first row of largest |entry| (a NaN entry is never the maximum: fmax drops it)
         double big = -1.0;
-#pragma unroll
-        for (int r = t; r < KD; ++r) big = fmax(big, fabs(E[r][t]));
         int p = t;
+        if (PERM && t == 0) {
+            big = big0;   // chosen while loading; row p0 already sits at position 0
+        } else {
 #pragma unroll
-        for (int r = KD - 1; r >= t; --r) p = (fabs(E[r][t]) == big) ? r : p;   // descending: the first wins
+            for (int r = t; r < KD; ++r) big = fmax(big, fabs(E[r][t]));
+#pragma unroll
+            for (int r = KD - 1; r >= t; --r) p = (fabs(E[r][t]) == big) ? r : p;   // descending: the first wins
+        }
         if (!(big > 0.0)) sing = true;
         minp = fmin(minp, big);
         maxp = fmax(maxp, big);
         // rotate row p to position t (columns t..KD-1 and the rhs)
+        if (!(PERM && t == 0))
 #pragma unroll
         for (int cc = t; cc <= KD; ++cc) {
             double pr = (cc < KD) ? E[t][cc < KD ? cc : 0] : H[t];
