@@ -61,25 +61,58 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     double E[KD][KD], H[KD];
     // PERM (tableau in LDS): step 0's pivot row is chosen BEFORE the rows are loaded — the entries
     // are still the tableau's own, so instead of loading rows 0..KD-1 and rotating the chosen one
-    // to the front (2 x (KD-1) selects per element: the largest single cost of a subset), column
-    // c[0] is read first, and the rows then come from LDS already in their rotated order: position
-    // 0 = row p, positions 1.. = the other rows ascending.  (Not for the thin kernel's records in
-    // HBM: a second dependent round trip costs more there than the selects.)
-    int p0 = 0;
-    double big0 = -1.0;
+    // to the front (2 x (KD-1) selects per element: the largest single cost of a subset), columns
+    // c[0] and c[1] are read first, and the rows then come from LDS already in their rotated
+    // order: position 0 = step 0's row, position 1 = step 1's, then the other rows ascending.
+    // (Not for the thin kernel's records in HBM: a second dependent round trip costs more there
+    // than the selects.)
+    // The same for step 1: its pivot row is the first largest entry of column c[1] AFTER step 0's
+    // elimination, among the rows other than p0 — five fmas on the two columns already read (the
+    // same operations, operand for operand, that step 0 performs on the loaded matrix below).
+    double big0 = -1.0, bigs1 = -1.0;
     if constexpr (PERM) {
-        double col0[KD];
+        double col0[KD], col1[KD];
         const double* cz = tab + c[0] * STRIDE;
+        const double* cy = tab + c[1] * STRIDE;
 #pragma unroll
-        for (int r = 0; r < KD; ++r) col0[r] = cz[r];
+        for (int r = 0; r < KD; ++r) {
+            col0[r] = cz[r];
+            col1[r] = cy[r];
+        }
+        int p0 = 0;
 #pragma unroll
         for (int r = 0; r < KD; ++r) big0 = fmax(big0, fabs(col0[r]));
 #pragma unroll
         for (int r = KD - 1; r >= 0; --r) p0 = (fabs(col0[r]) == big0) ? r : p0;   // descending: the first wins
+        double piv0 = col0[0], pr01 = col1[0];   // the pivot element and the pivot row's entry in column c[1]
+#pragma unroll
+        for (int r = 1; r < KD; ++r) {
+            piv0 = (r == p0) ? col0[r] : piv0;
+            pr01 = (r == p0) ? col1[r] : pr01;
+        }
+        const double inv0 = 1.0 / piv0;
+        double a1[KD];
+#pragma unroll
+        for (int r = 0; r < KD; ++r) {
+            const double u = fma(-(col0[r] * inv0), pr01, col1[r]);
+            a1[r] = (r == p0) ? -1.0 : fabs(u);
+        }
+#pragma unroll
+        for (int r = 0; r < KD; ++r) bigs1 = fmax(bigs1, a1[r]);
+        int q1 = 0;
+#pragma unroll
+        for (int r = KD - 1; r >= 0; --r) q1 = (a1[r] == bigs1) ? r : q1;
+        q1 = (bigs1 < 0.0) ? (p0 == 0 ? 1 : 0) : q1;   // (all NaN: any row other than p0; the subset is singular)
         int row[KD];
         row[0] = p0;
+        row[1] = q1;
+        const int lo = p0 < q1 ? p0 : q1, hi = p0 < q1 ? q1 : p0;
 #pragma unroll
-        for (int i = 1; i < KD; ++i) row[i] = (i - 1 < p0) ? i - 1 : i;
+        for (int k = 0; k < KD - 2; ++k) {
+            int idx = k + (k >= lo ? 1 : 0);
+            idx += (idx >= hi) ? 1 : 0;
+            row[k + 2] = idx;
+        }
 #pragma unroll
         for (int t = 0; t < KD; ++t) {
             const double* col = tab + c[t] * STRIDE;
@@ -111,8 +144,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         // first row of largest |entry| (a NaN entry is never the maximum: fmax drops it)
         double big = -1.0;
         int p = t;
-        if (PERM && t == 0) {
-            big = big0;   // chosen while loading; row p0 already sits at position 0
+        if (PERM && t <= 1) {
+            big = t == 0 ? big0 : bigs1;   // chosen while loading; the pivot rows already sit at positions 0, 1
         } else {
 #pragma unroll
             for (int r = t; r < KD; ++r) big = fmax(big, fabs(E[r][t]));
@@ -123,7 +156,7 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         minp = fmin(minp, big);
         maxp = fmax(maxp, big);
         // rotate row p to position t (columns t..KD-1 and the rhs)
-        if (!(PERM && t == 0))
+        if (!(PERM && t <= 1))
 #pragma unroll
         for (int cc = t; cc <= KD; ++cc) {
             double pr = (cc < KD) ? E[t][cc < KD ? cc : 0] : H[t];
