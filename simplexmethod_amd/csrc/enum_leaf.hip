@@ -311,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
             for (int a = last + 1; a <= lim; ++a) {
                 const int R = n - 1 - a;
                 const unsigned long long L = s_b6[R];
-                if (R >= min_child_R && (a - last - 1) % kItemLanes == sub) {
+                if (R >= min_child_R && ((a - last - 1) >> 1) % kItemLanes == sub) {
                     // groups j2 = 0, 1, ... with at least kGrandMin columns left; consecutive small
                     // groups are packed into one item (the child pivot is paid once per item)
                     unsigned long long off2 = 0, pack_off = 0, pack_n = 0;
@@ -340,7 +340,24 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
                         off2 += cnt2;
                     }
                     flush();
-                    chunks(rb, off2, L, [&](int lo) { emit(0, a, lo, (int)(rb - rb0)); });
+                    // table 0: what is left of the child, [off2, L) — at most C(kGrandMin, 6) subsets.
+                    // Children 2k and 2k+1 of a record share one item (k_enum_leaves<1> pivots both
+                    // from the one record and fills its passes from both tails), emitted by the even one.
+                    const bool odd = (a - last - 1) & 1;
+                    const bool mine = overlap(rb + off2, L - off2, begin, end) != 0ULL;
+                    bool partner = false;   // does the other child of the pair exist and overlap?
+                    if (!odd && a + 1 <= lim && n - 2 - a >= min_child_R) {
+                        const int Rn = R - 1;
+                        unsigned long long offn = 0;
+                        for (int j2 = 0; Rn - 1 - j2 >= kGrandMin; ++j2) offn += s_b5[Rn - 1 - j2];
+                        partner = overlap(rb + L + offn, s_b6[Rn] - offn, begin, end) != 0ULL;
+                    }
+                    if (odd) {
+                        // (its tail rides in the even child's item: that one is emitted whenever either
+                        // tail meets the range)
+                    } else if (mine || partner) {
+                        emit(0, a | (partner ? 1 << 16 : 0), (int)off2, (int)(rb - rb0));
+                    }
                 }
                 rb += L;
             }
@@ -407,6 +424,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     constexpr int CHILDCOLS = NMX + KD + 1;                  // columns of a depth m-6 tableau (+ rhs)
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
     __shared__ __attribute__((aligned(16))) double s_child[FUSED ? LEAF_WAVES : 1][FUSED ? CHILDCOLS * TS : 1];
+    __shared__ __attribute__((aligned(16))) double s_child2[MODE == 1 ? LEAF_WAVES : 1][MODE == 1 ? CHILDCOLS * TS : 1];
     __shared__ __attribute__((aligned(16))) double s_grand[MODE == 2 ? LEAF_WAVES : 1][MODE == 2 ? (NMX + KD) * TS : 1];
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
     __shared__ unsigned long long s_cnt[3];
@@ -507,6 +525,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
         const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
         double minp0 = pm.minp, maxp0 = pm.maxp;
         unsigned umask = __builtin_amdgcn_readfirstlane(pm.used_mask);
+        bool sing0 = false;   // MODE 1: the first child of a paired item turned out singular
         if (FUSED) {
             // ---- the wave pivots on column `child`: lane = (row r, column group g), exactly the
             // arithmetic of k_enum_expand (first unused row of largest |w|; l = -(w/piv) as w * (1/piv))
@@ -527,7 +546,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                     if (ngroups == 1) span = min(span - leaf_lo, (unsigned int)kChunk);
                 }
                 if (lane == 0) cntS += (unsigned int)overlap(rb + leaf_lo, span, begin, end);
-                continue;
+                if (MODE == 1 && ((child >> 16) & 1))
+                    sing0 = true;   // the item's second child is still to do
+                else
+                    continue;
             }
             const double inv = 1.0 / pcol[p];
             const bool isp = (r == p);
@@ -544,7 +566,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
 #pragma unroll
             for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
                 const int j = g + 4 * q;            // child column j = column child+1+j (j = R: rhs)
-                if (j <= R) {
+                if (j <= R && !sing0) {
                     const double* pc = tab + (child_col + 1 + j - D) * TS;
                     ctab[j * TS + pos] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
                 }
@@ -612,6 +634,77 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                     if (at < pd.list_cap) pd.list[at] = rank;
                 }
             }
+            }
+        } else if constexpr (MODE == 1) {
+            // ---- table 0 item: the tail [leaf_lo, L) of child `child_col` and, if flagged, of the next
+            // child too (pivoted from the same record): the lanes are filled from both tails
+            const bool pair = (child >> 16) & 1;
+            const double* par = s_tab[wave * 2 + (buf ^ 1)];   // the record's slice (tab now points at the child)
+            unsigned int T0 = sing0 ? 0u : L - leaf_lo, T1 = 0, lo1 = 0;
+            unsigned long long rb1 = rb + L;
+            double minq = pm.minp, maxq = pm.maxp;
+            const double* tab1 = tab;
+            int R1 = R - 1;
+            if (pair) {
+                for (int j2 = 0; R1 - 1 - j2 >= kGrandMin; ++j2) lo1 += s_binom[(R1 - 1 - j2) * (KD + 1) + KD - 1];
+                const unsigned int L1 = s_binom[R1 * (KD + 1) + KD];
+                T1 = L1 - lo1;
+                // second pivot, on column child_col + 1 of the record
+                const int r = lane & (PG - 1), g = lane >> 4;
+                unsigned um1 = __builtin_amdgcn_readfirstlane(pm.used_mask);
+                const bool row_used = (r >= m) || ((um1 >> r) & 1u);
+                const double* pcol = par + (child_col + 1 - D) * TS;
+                const double w = pcol[r];
+                double big;
+                const int p = __builtin_amdgcn_readfirstlane(pick_pivot_row(w, row_used, lane & ~(PG - 1), big));
+                minq = fmin(minq, big);
+                maxq = fmax(maxq, big);
+                if (!(big > 0.0) || minq <= DBL_EPSILON * (double)m * maxq) {
+                    if (lane == 0) cntS += (unsigned int)overlap(rb1 + lo1, T1, begin, end);
+                    T1 = 0;   // every subset below the second child is singular
+                } else {
+                    const double inv = 1.0 / pcol[p];
+                    const bool isp = (r == p);
+                    const double lx = isp ? inv : -(w * inv);
+                    um1 |= 1u << p;
+                    const unsigned all = (1u << m) - 1u, below = (1u << r) - 1u, freem = ~um1 & all;
+                    const int pos = (r >= m) ? r
+                                    : ((freem >> r) & 1u) ? __builtin_popcount(freem & below)
+                                                          : __builtin_popcount(freem) + __builtin_popcount(um1 & all & below);
+                    double* ctab1 = s_child2[wave];
+#pragma unroll
+                    for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
+                        const int j = g + 4 * q;        // column j of the second child = record column child_col+2+j
+                        if (j <= R1) {
+                            const double* pc = par + (child_col + 2 + j - D) * TS;
+                            ctab1[j * TS + pos] = fma(lx, pc[p], isp ? -0.0 : pc[r]);
+                        }
+                    }
+                    tab1 = ctab1;
+                }
+            }
+            const unsigned* comb1 = pd.comb6 + s_off[R1 >= KD ? R1 : KD];
+            const int U[KD] = {0, 1, 2, 3, 4, 5};        // unused by leaf_verdict<PERM>
+            for (unsigned int gidx = lane; gidx < T0 + T1; gidx += 64) {
+                const bool second = gidx >= T0;
+                const unsigned int leaf = second ? lo1 + (gidx - T0) : leaf_lo + gidx;
+                const unsigned long long rank = (second ? rb1 : rb) + leaf;
+                if (rank < begin || rank >= end) continue;
+                int c[KD];
+                const unsigned pk = (second ? comb1 : comb)[leaf];
+#pragma unroll
+                for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
+                const int verdict = leaf_verdict<KD, TS, true>(second ? tab1 : tab, c, second ? R1 : R, U, 0u,
+                                                               second ? minq : minp0, second ? maxq : maxp0, m);
+                if (verdict == 2) {
+                    ++cntS;
+                } else if (verdict == 1) {
+                    ++cntI;
+                } else {
+                    ++cntF;
+                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                    if (at < pd.list_cap) pd.list[at] = rank;
+                }
             }
         } else {
         const int U[KD] = {0, 1, 2, 3, 4, 5};        // unused by leaf_verdict<PERM>
