@@ -188,7 +188,7 @@ void lp_batched_free(lp_batched_problem* p);
 uint64_t lp_binom(int n, int k); /* C(n,k), 0 on overflow */
 /* Shard `shard` of `shards` contiguous rank ranges of EQUAL ESTIMATED COST for the shared-prefix
  * enumeration (the rank space shards across the GPUs of a node): cost(x) = x +
- * 180 * (depth m-7 tree nodes before subset x) — late prefixes have few subsets per node, and
+ * 170 * (depth m-7 tree nodes before subset x) — late prefixes have few subsets per node, and
  * equal-size shards differ by 1.5x in run time.  Pure host arithmetic; the solver's answer does
  * not depend on where the cuts are (tie rule).  Small problems get equal-size ranges.         */
 int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_out,
