@@ -195,7 +195,7 @@ def cpu_baseline_leg(args):
     from simplexmethod_amd import capi
     m, n = args.enum_m, args.enum_n
     A, b, c, _ = capi.gen_lp(0, m, n)
-    sample = 4_000_000
+    sample = 12_000_000
     total = o.binom(n, m)
     sample = min(sample, total)
     t0 = time.perf_counter()
@@ -203,7 +203,7 @@ def cpu_baseline_leg(args):
     t_enum = time.perf_counter() - t0
     pm, pn = args.pivot_m, args.pivot_n
     A2, b2, c2, basis2 = capi.gen_lp(0, pm, pn)
-    piv = 12
+    piv = 40
     t0 = time.perf_counter()
     r = o.simplex_reference(A2, b2, c2, basis2, True, pn - pm, max_iter=piv, dense_eta_product=True)
     t_piv = time.perf_counter() - t0

@@ -245,7 +245,7 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
     return sel;
 }
 
-__global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
+__global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = d.m, n = d.n, nn = n - m, W = nn + 1, pitch = d.pitch;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -291,41 +291,44 @@ __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
     const double eps = d.eps;
     int iters = 0;
     int status = kRunning;
-    // flattened (row, column) walk of the tableau: element idx = i*W + j
-    const int step_i = nt / W, step_j = nt - step_i * W;
-    const int i0 = tid / W, j0 = tid - i0 * W;
-    const int total = (m + 1) * W;
-
     const int wave = tid >> 6, lane = tid & 63;
     int* pub = &rs->a[0][0];   // [0] entering slot, [1] leaving position, published by wave 0
+    // Pricing over the non-basic slots, keyed by variable index (:152-174): wave 0 alone.  It runs
+    // for pivot k+1 WHILE the other waves apply pivot k's update to the constraint rows: wave 0
+    // updates the reduced-cost row first, which is all the pricing reads.
+    auto price = [&]() {
+        double best;
+        const double* drow = T + (size_t)m * pitch;
+        auto getd = [&](int s, double& v, int& k, bool& ok) {
+            v = drow[s];
+            k = slotvar[s];
+            ok = true;
+        };
+        int se0 = d.maximize ? wave_scan_keyed<true>(nn, eps, best, getd)
+                             : wave_scan_keyed<false>(nn, eps, best, getd);
+        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
+        if (optimal) se0 = -1;
+        if (lane == 0) pub[0] = se0;
+    };
+    // the waves other than wave 0 update the constraint rows: ugroups threads per column
+    const int unt = nt - 64, ut = tid - 64;
+    const int ugroups = unt / W > 0 ? unt / W : 1;
+    if (wave == 0) price();
     while (true) {
+        __syncthreads();   // tableau complete, pub[0] published
         if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
             status = LP_ITER_LIMIT;
             break;
         }
-        // ---- pricing over the non-basic slots, keyed by variable index (:152-174): wave 0 alone
-        if (wave == 0) {
-            double best;
-            const double* drow = T + (size_t)m * pitch;
-            auto getd = [&](int s, double& v, int& k, bool& ok) {
-                v = drow[s];
-                k = slotvar[s];
-                ok = true;
-            };
-            int se = d.maximize ? wave_scan_keyed<true>(nn, eps, best, getd)
-                                : wave_scan_keyed<false>(nn, eps, best, getd);
-            const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
-            if (optimal) se = -1;
-            if (lane == 0) pub[0] = se;
-        }
-        __syncthreads();
         const int se = pub[0];
         if (se < 0) {
             status = LP_OPTIMAL;
             break;
         }
         // ---- entering column, unbounded test (:176-179), ratios (:185-186) and the ratio test
-        // keyed by basis position (:181-194; +inf entries are never taken): wave 0 alone
+        // keyed by basis position (:181-194; +inf entries are never taken): wave 0 alone (computing
+        // the ratios with all threads first and scanning an LDS array was measured slower: one more
+        // barrier than the divisions cost)
         if (wave == 0) {
             int any_pos = 0;
             for (int i = lane; i < m; i += 64)
@@ -354,53 +357,45 @@ __global__ __launch_bounds__(512) void k_batched_simplex(BatchedDev d) {
         for (int i = tid; i <= m; i += nt)
             lcol[i] = (i == r) ? inv : -T[(size_t)i * pitch + se] / ur;
         __syncthreads();
-        // ---- rank-1 update of every stored element; slot se receives the leaving column.
-        // Four elements per thread and step, so that their LDS reads are in flight together.
-        {
-            int i = i0, j = j0;
-            for (int idx = tid; idx < total; idx += 4 * nt) {
-                int ii[4], jj[4];
-                bool ok[4];
-                double l[4], pr[4], old[4];
+        // ---- rank-1 update of every stored element; slot se receives the leaving column
+        if (wave == 0) {
+            // the reduced-cost row, the basis bookkeeping, then the next pivot's pricing
+            const double lm = lcol[m];
+            double* drow = T + (size_t)m * pitch;
+            for (int j = lane; j < W; j += 64) drow[j] = (j == se) ? lm : fma(lm, prow[j], drow[j]);
+            if (lane == 0) {
+                const int ve = slotvar[se];
+                slotvar[se] = basis[r];
+                basis[r] = ve;  // N(leave_pos) = enter, :196
+            }
+            price();
+        } else {
+            // the constraint rows: a thread owns one column (its pivot-row entry stays in a register)
+            // and every ugroups-th row; four rows per step so that their LDS reads are in flight
+            // together.  Column se receives the leaving column (the eta column itself).
+            for (int slot = ut; slot < ugroups * W; slot += unt) {   // (one slot per thread unless W > unt)
+                const int j = slot % W, g = slot / W;
+                const double pj = prow[j];
+                const bool is_se = (j == se);
+                for (int i = g; i < m; i += 4 * ugroups) {
+                    double l[4], old[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ii[u] = i;
-                    jj[u] = j;
-                    ok[u] = idx + u * nt < total;
-                    i += step_i;
-                    j += step_j;
-                    if (j >= W) {
-                        j -= W;
-                        ++i;
+                    for (int u = 0; u < 4; ++u) {
+                        const int iu = i + u * ugroups;
+                        const int ic = iu < m ? iu : 0;
+                        l[u] = lcol[ic];
+                        old[u] = T[(size_t)ic * pitch + j];
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ic = ok[u] ? ii[u] : 0, jc = ok[u] ? jj[u] : 0;
-                    l[u] = lcol[ic];
-                    pr[u] = prow[jc];
-                    old[u] = T[(size_t)ic * pitch + jc];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    double t;
-                    if (jj[u] == se)
-                        t = l[u];
-                    else if (ii[u] == r)
-                        t = pr[u] * l[u];
-                    else
-                        t = fma(l[u], pr[u], old[u]);
-                    if (ok[u]) T[(size_t)ii[u] * pitch + jj[u]] = t;
+                    for (int u = 0; u < 4; ++u) {
+                        const int iu = i + u * ugroups;
+                        const double t = is_se ? l[u] : (iu == r) ? pj * l[u] : fma(l[u], pj, old[u]);
+                        if (iu < m) T[(size_t)iu * pitch + j] = t;
+                    }
                 }
             }
         }
-        if (tid == 0) {
-            const int ve = slotvar[se];
-            slotvar[se] = basis[r];
-            basis[r] = ve;  // N(leave_pos) = enter, :196
-        }
         ++iters;
-        __syncthreads();
     }
     __syncthreads();
     // ---- outputs: x(N(t)) = xB(t), zeros elsewhere (:131-132); basis; counters
@@ -432,6 +427,6 @@ int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
     const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);
     LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_batched_simplex, d.batch, 512, shm, ctx->stream, d);
+    hipLaunchKernelGGL(k_batched_simplex, d.batch, 1024, shm, ctx->stream, d);
     return LP_OPTIMAL;
 }

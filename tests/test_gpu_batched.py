@@ -27,7 +27,7 @@ def _check(g, A, b, c, basis, maximize, n_orig, max_iter=capi.MAX_ITER):
 
 
 @pytest.mark.parametrize("m,n,count", [(2, 5, 7), (8, 16, 33), (16, 40, 20), (32, 64, 40),
-                                        (64, 128, 24), (128, 256, 48)])
+                                        (64, 128, 24), (128, 256, 48), (12, 1012, 6)])
 def test_batched_matches_oracle(ctx, m, n, count):
     A, b, c, basis = _batch(range(100, 100 + count), m, n)
     g = ctx.simplex_solve_batched(A, b, c, basis, True, n - m)
