@@ -97,7 +97,10 @@ __device__ __forceinline__ void solve_subset(const EnumDev& d, const double* sA,
     for (int t = 0; t < G; ++t) {
         out.P[t] = 0;
         if (t < g) {
-            double a = used ? -1.0 : fabs(W[t]);
+            // (a NaN entry is never the maximum — oracle: `a > big` is false for it; here it must not
+            // enter the butterfly either, where it would survive every comparison)
+            const double aw = fabs(W[t]);
+            double a = (used || !(aw >= 0.0)) ? -1.0 : aw;
             int idx = gl;
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {

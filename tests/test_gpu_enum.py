@@ -261,6 +261,27 @@ def test_prefix_all_singular(ctx):
     p.free()
 
 
+@pytest.mark.parametrize("m,n", [(8, 20), (9, 24)])
+def test_prefix_nan_and_inf_entries(ctx, m, n):
+    """NaN / inf in the data: a NaN is never a pivot maximum, and a subset whose solution holds a
+    NaN counts as infeasible (Canonical.cpp:171 compares x >= -1e-9) — same verdicts, subset by
+    subset, as the oracle, on both kernels."""
+    A, b, c, _ = lpcases.random_lp(300 + n, m, n)
+    A[2, 1] = np.nan
+    A[5, n // 2] = np.inf
+    A[m - 1, n - 3] = -np.inf
+    A[0, 3] = np.nan
+    b[m - 2] = np.nan
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    p = ctx.enum_problem(A, b, c, True)
+    for algo in (capi.ENUM_PREFIX, capi.ENUM_DIRECT):
+        rc, gz, gcounts, _ = p.range(0, total, algo)
+        assert gcounts == counts and rc == st
+        assert gz == z or (np.isnan(gz) and np.isnan(z))
+    p.free()
+
+
 def test_prefix_rejects_unsupported_shapes(ctx):
     A, b, c, _ = lpcases.random_lp(1, 3, 7)
     p = ctx.enum_problem(A, b, c, True)
