@@ -147,7 +147,7 @@ def test_golden_vectors_gpu(ctx):
 # ---- shared-prefix path (enum_prefix.hip): same answers as the oracle, bit for bit ------------
 
 PREFIX_SHAPES = [(6, 12, 51), (7, 16, 52), (8, 16, 53), (10, 20, 54), (6, 20, 55), (8, 24, 56),
-                 (12, 20, 57), (16, 20, 58)]
+                 (12, 20, 57), (16, 20, 58), (9, 25, 59), (11, 23, 60), (15, 22, 61), (7, 9, 62)]
 
 
 @pytest.mark.parametrize("m,n,seed", PREFIX_SHAPES)
@@ -161,6 +161,8 @@ def test_prefix_matches_oracle(ctx, m, n, seed):
     assert rc == st and gz == z
     k = o.enum_first_within(A, b, c, True, 0, total, z)
     assert p.first_within(0, total, z) == k
+    # a wider tolerance does not go through the tie rule cached by the range pass
+    assert p.first_within(0, total, z, 1e-2 * abs(z)) == o.enum_first_within(A, b, c, True, 0, total, z, 1e-2 * abs(z))
     v = p.vertex(k)
     _, xB, zz = o.enum_subset(A, b, c, o.unrank(n, m, k))
     assert v["obj"] == zz and np.array_equal(v["x"][v["basis"]], xB)
