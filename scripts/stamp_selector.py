@@ -18,7 +18,7 @@ out = np.zeros(cap * 8, dtype=np.uint64)
 ctx.lib.lp_debug_simplex_stamps(p.h, cap, out.ctypes.data_as(C.POINTER(C.c_uint64)))
 s = out.reshape(cap, 8)[:min(cap, st.pivots)].astype(np.int64)
 dt = np.diff(s, axis=1)
-names = ["pricing chain", "column e (HBM+etas)", "ratio chain", "pivot row (HBM+etas)+d", "eta col + xB", "bookkeeping", "barrier"]
+names = ["pricing chain", "column e (HBM+etas)", "ratio chain", "eta col + xB (under the row read)", "pivot row (etas)+d", "bookkeeping", "barrier"]
 print("pivots", st.pivots, "solve_ms", st.solve_ms, "us/pivot", 1e3 * st.solve_ms / st.pivots)
 print("median ticks per phase (s_memtime, 100 MHz?):")
 for k, nm in enumerate(names):

@@ -187,11 +187,23 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         const double lm = -s.d[e] / ur;    // F row of the reduced costs
         const double rhs_r = s.rhs[r];
         __syncthreads();                   // everyone has read d[e], rhs[r] before they change
-        // ---- pivot row of the CURRENT tableau (before scaling) + reduced-cost update
+        // ---- pivot row of the CURRENT tableau (before scaling) + reduced-cost update.  The stale
+        // row's HBM read is issued first and the eta column + xB update (LDS only) run under it.
         double* prS = s.prH + (size_t)sidx * (n + 1);
         double* etaP = la.etaP + (size_t)sidx * ld;
+        const double t_first = (tid < n) ? T[(size_t)r * ld + tid] : 0.0;
+        // ---- eta column (:198-204) + xB update
+        double* lcS = s.lcH + (size_t)sidx * m;
+        double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
+        for (int i = tid; i < m; i += SEL_THREADS) {
+            const double l = (i == r) ? inv : -s.u[i] / ur;
+            lcS[i] = l;
+            etaL[i] = l;
+            s.rhs[i] = (i == r) ? rhs_r * inv : fma(l, rhs_r, s.rhs[i]);
+        }
+        LP_STAMP(4);
         for (int j = tid; j < n; j += SEL_THREADS) {
-            double t = T[(size_t)r * ld + j];
+            double t = (j == tid) ? t_first : T[(size_t)r * ld + j];
 #pragma unroll 4
             for (int q = 0; q < sidx; ++q) {
                 const QInfo qi = s.qi[q];
@@ -204,16 +216,6 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
             etaP[j] = t;
             const double dj = fma(lm, t, s.d[j]);
             s.d[j] = (j == e) ? 0.0 : dj;
-        }
-        LP_STAMP(4);
-        // ---- eta column (:198-204) + xB update
-        double* lcS = s.lcH + (size_t)sidx * m;
-        double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
-        for (int i = tid; i < m; i += SEL_THREADS) {
-            const double l = (i == r) ? inv : -s.u[i] / ur;
-            lcS[i] = l;
-            etaL[i] = l;
-            s.rhs[i] = (i == r) ? rhs_r * inv : fma(l, rhs_r, s.rhs[i]);
         }
         LP_STAMP(5);
         if (tid == 0) {
