@@ -81,6 +81,9 @@ int lp_context_create(int device, void* stream, lp_context** ctx_out) {
 
 void lp_context_destroy(lp_context* ctx) {
     if (!ctx) return;
+    for (auto& b : ctx->pool) (void)hipFree(b.first);
+    (void)hipFree(ctx->dcomb6);
+    (void)hipFree(ctx->dcomb5);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -533,11 +536,16 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->dev.result); (void)hipFree(p->dev.chunk_best);
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
-    (void)hipFree(p->prefix.root_cursor); (void)hipFree(p->prefix.list);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->prefix.scores); (void)hipFree(p->dpairtab); (void)hipFree(p->dcomb6); (void)hipFree(p->dcomb5);
-    (void)hipFree(p->prefix.items); (void)hipFree(p->prefix.items2); (void)hipFree(p->prefix.item_count);
+    (void)hipFree(p->prefix.root_cursor);
+    lp_pool_release(p->ctx, p->prefix.list, sizeof(unsigned long long) * p->prefix.list_cap);
+    lp_pool_release(p->ctx, p->prefix.scores, sizeof(double) * p->prefix.list_cap);
+    (void)hipFree(p->prefix.list_count); (void)hipFree(p->dpairtab);
+    lp_pool_release(p->ctx, p->prefix.items, sizeof(int4) * (size_t)p->prefix.item_cap);
+    lp_pool_release(p->ctx, p->prefix.items2, sizeof(int4) * (size_t)p->prefix.item_cap2);
+    (void)hipFree(p->prefix.item_count);
     if (p->h_item_count) (void)hipHostFree(p->h_item_count);
-    (void)hipFree(p->prefix_buf[0]); (void)hipFree(p->prefix_buf[1]);
+    lp_pool_release(p->ctx, p->prefix_buf[0], p->prefix_buf_bytes[0]);
+    lp_pool_release(p->ctx, p->prefix_buf[1], p->prefix_buf_bytes[1]);
     if (p->h_level_counts) (void)hipHostFree(p->h_level_counts);
     if (p->h_list_count) (void)hipHostFree(p->h_list_count);
     if (p->h_overflow) (void)hipHostFree(p->h_overflow);
@@ -611,9 +619,12 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
         LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
-        LP_TRY(hipMalloc(&pd.list, sizeof(unsigned long long) * pd.list_cap));
+        {
+            size_t got = 0;
+            LP_TRY(lp_pool_alloc(ctx, (void**)&pd.list, sizeof(unsigned long long) * pd.list_cap, &got));
+            LP_TRY(lp_pool_alloc(ctx, (void**)&pd.scores, sizeof(double) * pd.list_cap, &got));
+        }
         LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
-        LP_TRY(hipMalloc(&pd.scores, sizeof(double) * pd.list_cap));
         LP_TRY(hipMalloc(&p->dpairtab, sizeof(unsigned short) * pairtab.size()));
         LP_TRY(hipHostMalloc(&p->h_level_counts, sizeof(int) * 32));
         LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
@@ -621,45 +632,47 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipMemcpyAsync(p->dpairtab, pairtab.data(), sizeof(unsigned short) * pairtab.size(),
                               hipMemcpyHostToDevice, s));
         pd.pairtab = p->dpairtab;
-        // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
-        std::vector<unsigned> comb6(32, 0u);
-        for (int R = 6; R <= 22; ++R) {
-            comb6[(size_t)R] = (unsigned)comb6.size();
-            int s6[6] = {0, 1, 2, 3, 4, 5};
-            for (;;) {
-                unsigned pk = 0;
-                for (int t = 0; t < 6; ++t) pk |= (unsigned)s6[t] << (5 * t);
-                comb6.push_back(pk);
-                int t = 5;
-                while (t >= 0 && s6[t] == R - 6 + t) --t;
-                if (t < 0) break;
-                ++s6[t];
-                for (int u = t + 1; u < 6; ++u) s6[u] = s6[u - 1] + 1;
+        if (!ctx->dcomb6 || !ctx->dcomb5) {   // (shape-independent: once per context)
+            // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
+            std::vector<unsigned> comb6(32, 0u);
+            for (int R = 6; R <= 22; ++R) {
+                comb6[(size_t)R] = (unsigned)comb6.size();
+                int s6[6] = {0, 1, 2, 3, 4, 5};
+                for (;;) {
+                    unsigned pk = 0;
+                    for (int t = 0; t < 6; ++t) pk |= (unsigned)s6[t] << (5 * t);
+                    comb6.push_back(pk);
+                    int t = 5;
+                    while (t >= 0 && s6[t] == R - 6 + t) --t;
+                    if (t < 0) break;
+                    ++s6[t];
+                    for (int u = t + 1; u < 6; ++u) s6[u] = s6[u - 1] + 1;
+                }
             }
-        }
-        LP_TRY(hipMalloc(&p->dcomb6, sizeof(unsigned) * comb6.size()));
-        LP_TRY(hipMemcpyAsync(p->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
-        // second level of the leaf kernel: every 5-subset of R <= 21 columns, same packing
-        std::vector<unsigned> comb5(32, 0u);
-        for (int R = 5; R <= 21; ++R) {
-            comb5[(size_t)R] = (unsigned)comb5.size();
-            int s5[5] = {0, 1, 2, 3, 4};
-            for (;;) {
-                unsigned pk = 0;
-                for (int t = 0; t < 5; ++t) pk |= (unsigned)s5[t] << (5 * t);
-                comb5.push_back(pk);
-                int t = 4;
-                while (t >= 0 && s5[t] == R - 5 + t) --t;
-                if (t < 0) break;
-                ++s5[t];
-                for (int u = t + 1; u < 5; ++u) s5[u] = s5[u - 1] + 1;
+            LP_TRY(hipMalloc(&ctx->dcomb6, sizeof(unsigned) * comb6.size()));
+            LP_TRY(hipMemcpyAsync(ctx->dcomb6, comb6.data(), sizeof(unsigned) * comb6.size(), hipMemcpyHostToDevice, s));
+            // second level of the leaf kernel: every 5-subset of R <= 21 columns, same packing
+            std::vector<unsigned> comb5(32, 0u);
+            for (int R = 5; R <= 21; ++R) {
+                comb5[(size_t)R] = (unsigned)comb5.size();
+                int s5[5] = {0, 1, 2, 3, 4};
+                for (;;) {
+                    unsigned pk = 0;
+                    for (int t = 0; t < 5; ++t) pk |= (unsigned)s5[t] << (5 * t);
+                    comb5.push_back(pk);
+                    int t = 4;
+                    while (t >= 0 && s5[t] == R - 5 + t) --t;
+                    if (t < 0) break;
+                    ++s5[t];
+                    for (int u = t + 1; u < 5; ++u) s5[u] = s5[u - 1] + 1;
+                }
             }
+            LP_TRY(hipMalloc(&ctx->dcomb5, sizeof(unsigned) * comb5.size()));
+            LP_TRY(hipMemcpyAsync(ctx->dcomb5, comb5.data(), sizeof(unsigned) * comb5.size(), hipMemcpyHostToDevice, s));
+            LP_TRY(hipStreamSynchronize(s));  // comb6 / comb5 are locals
         }
-        LP_TRY(hipMalloc(&p->dcomb5, sizeof(unsigned) * comb5.size()));
-        LP_TRY(hipMemcpyAsync(p->dcomb5, comb5.data(), sizeof(unsigned) * comb5.size(), hipMemcpyHostToDevice, s));
-        LP_TRY(hipStreamSynchronize(s));  // comb6 / comb5 are locals
-        pd.comb6 = p->dcomb6;
-        pd.comb5 = p->dcomb5;
+        pd.comb6 = ctx->dcomb6;
+        pd.comb5 = ctx->dcomb5;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

@@ -821,11 +821,12 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     const uint64_t total = lp_host_binom(n, m);
     auto ensure = [&](int4*& items, int& cap, uint64_t want) -> int {
         if ((uint64_t)cap >= want) return LP_OPTIMAL;
-        if (items) (void)hipFree(items);
+        lp_pool_release(ctx, items, sizeof(int4) * (size_t)cap);
         items = nullptr;
         cap = 0;
-        LP_HIP(ctx, hipMalloc(&items, sizeof(int4) * want));
-        cap = (int)std::min<uint64_t>(want, 0x7FFFFFFFULL);
+        size_t got = 0;
+        LP_HIP(ctx, lp_pool_alloc(ctx, (void**)&items, sizeof(int4) * want, &got));
+        cap = (int)std::min<uint64_t>(got / sizeof(int4), 0x7FFFFFFFULL);
         return LP_OPTIMAL;
     };
     int rc = ensure(pd.items, pd.item_cap, bound6 + total / kChunk + 1024);

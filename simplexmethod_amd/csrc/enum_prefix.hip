@@ -736,21 +736,29 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const size_t need_prev = D0 >= 1 ? (size_t)lp_host_binom(n - m + D0 - 1, D0 - 1) * host_rec_doubles(n, D0 - 1) * sizeof(double)
                                      : (size_t)host_rec_doubles(n, 0) * sizeof(double);
     if (p->prefix_buf_bytes[0] < need) {
-        if (p->prefix_buf[0]) (void)hipFree(p->prefix_buf[0]);
+        lp_pool_release(ctx, p->prefix_buf[0], p->prefix_buf_bytes[0]);
         p->prefix_buf[0] = nullptr;
         p->prefix_buf_bytes[0] = 0;
         size_t free_b = 0, total_b = 0;
         LP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        if (need + need_prev > free_b / 10 * 9) {
+            // give back what the context's pool holds before giving up on this path
+            for (auto& b : ctx->pool) (void)hipFree(b.first);
+            ctx->pool.clear();
+            LP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        }
         if (need + need_prev > free_b / 10 * 9) return LP_ITER_LIMIT;  // caller falls back to direct
-        LP_HIP(ctx, hipMalloc(&p->prefix_buf[0], need));
-        p->prefix_buf_bytes[0] = need;
+        size_t got = 0;
+        LP_HIP(ctx, lp_pool_alloc(ctx, (void**)&p->prefix_buf[0], need, &got));
+        p->prefix_buf_bytes[0] = got;
     }
     if (p->prefix_buf_bytes[1] < need_prev) {
-        if (p->prefix_buf[1]) (void)hipFree(p->prefix_buf[1]);
+        lp_pool_release(ctx, p->prefix_buf[1], p->prefix_buf_bytes[1]);
         p->prefix_buf[1] = nullptr;
         p->prefix_buf_bytes[1] = 0;
-        LP_HIP(ctx, hipMalloc(&p->prefix_buf[1], need_prev));
-        p->prefix_buf_bytes[1] = need_prev;
+        size_t got = 0;
+        LP_HIP(ctx, lp_pool_alloc(ctx, (void**)&p->prefix_buf[1], need_prev, &got));
+        p->prefix_buf_bytes[1] = got;
     }
     // depth-D0 records always end in buffer 0; levels alternate so that level D0 lands there
     if (getenv("LP_ENUM_DEBUG") && !pd.dbg) {

@@ -92,8 +92,6 @@ struct lp_enum_problem {
     double* prefix_buf[2] = {nullptr, nullptr};
     size_t prefix_buf_bytes[2] = {0, 0};
     unsigned short* dpairtab = nullptr;
-    unsigned* dcomb6 = nullptr;
-    unsigned* dcomb5 = nullptr;
     int* h_item_count = nullptr;               // pinned
     int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned

@@ -17,7 +17,42 @@ struct lp_context {
     bool owns_stream = false;
     int num_cus = 0;
     std::string last_error;
+    // Large device buffers released by freed problems, kept for the next one (hipMalloc / hipFree of
+    // the enumeration's multi-GB level buffers cost milliseconds: more than a small solve).
+    std::vector<std::pair<void*, size_t>> pool;
+    // shape-independent subset tables of the enumeration's leaf kernels, built once per context
+    unsigned* dcomb6 = nullptr;
+    unsigned* dcomb5 = nullptr;
 };
+
+// Best-fit buffer of at least `bytes` from the context's pool (not more than twice as large), else
+// hipMalloc.  *got receives the actual size.
+inline hipError_t lp_pool_alloc(lp_context* ctx, void** out, size_t bytes, size_t* got) {
+    int best = -1;
+    for (int k = 0; k < (int)ctx->pool.size(); ++k) {
+        const size_t have = ctx->pool[(size_t)k].second;
+        if (have >= bytes && have <= 2 * bytes + (1u << 20) &&
+            (best < 0 || have < ctx->pool[(size_t)best].second))
+            best = k;
+    }
+    if (best >= 0) {
+        *out = ctx->pool[(size_t)best].first;
+        *got = ctx->pool[(size_t)best].second;
+        ctx->pool.erase(ctx->pool.begin() + best);
+        return hipSuccess;
+    }
+    *got = bytes;
+    return hipMalloc(out, bytes);
+}
+inline void lp_pool_release(lp_context* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    constexpr size_t kMaxPooled = 8;
+    if (bytes < (1u << 20) || ctx->pool.size() >= kMaxPooled) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool.emplace_back(p, bytes);
+}
 
 // HIP call check: records the message in the context and returns -(hipError_t).
 #define LP_HIP(ctx, expr)                                                                  \
