@@ -701,6 +701,15 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     uint64_t counts[3] = {0, 0, 0};
     p->list_valid = false;
     p->spec_valid = false;
+    if (algo != LP_ENUM_ALGO_AUTO && algo != LP_ENUM_ALGO_DIRECT && algo != LP_ENUM_ALGO_PREFIX)
+        LP_FAIL(ctx, LP_BAD_ARG, "unknown enumeration algorithm id");
+    if (rank_begin == rank_end) {   // an empty shard (more processes than subsets): nothing to launch
+        if (zbest_out) *zbest_out = p->dev.maximize ? -INFINITY : INFINITY;
+        if (counts_out)
+            for (int k = 0; k < 3; ++k) counts_out[k] = 0;
+        if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out));
+        return LP_INFEASIBLE;
+    }
     if (algo == LP_ENUM_ALGO_AUTO)  // the shared-prefix path pays off once the tree is deep and wide
         algo = (lp_enum_prefix_supported(p) && rank_end - rank_begin >= (1ULL << 20)) ? LP_ENUM_ALGO_PREFIX
                                                                                         : LP_ENUM_ALGO_DIRECT;

@@ -284,6 +284,23 @@ def test_prefix_nan_and_inf_entries(ctx, m, n):
     p.free()
 
 
+@pytest.mark.parametrize("m,n", [(10, 12), (12, 15), (16, 18)])
+def test_prefix_narrowest_trees_and_tiny_ranges(ctx, m, n):
+    """n - m = 2, 3: every node has two or three children; plus empty and one-subset ranges."""
+    A, b, c, _ = lpcases.random_lp(400 + n, m, n)
+    total = o.binom(n, m)
+    p = ctx.enum_problem(A, b, c, True)
+    ref = o.enum_range(A, b, c, True, 0, total)
+    assert p.range(0, total, capi.ENUM_PREFIX)[:3] == ref
+    assert p.range(0, total, capi.ENUM_DIRECT)[:3] == ref
+    for lo, hi in [(0, 1), (total - 1, total), (total // 2, total // 2 + 1), (3, 3), (total // 3, total // 3 + 7)]:
+        got = p.range(lo, hi, capi.ENUM_PREFIX)[:3]
+        want = o.enum_range(A, b, c, True, lo, hi) if hi > lo else (o.INFEASIBLE, -np.inf, [0, 0, 0])
+        assert got == want, (lo, hi)
+        assert p.range(lo, hi, capi.ENUM_DIRECT)[:3] == want, (lo, hi)
+    p.free()
+
+
 def test_prefix_rejects_unsupported_shapes(ctx):
     A, b, c, _ = lpcases.random_lp(1, 3, 7)
     p = ctx.enum_problem(A, b, c, True)
