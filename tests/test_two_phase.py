@@ -123,6 +123,30 @@ def test_gpu_bit_exact_vs_oracle(ctx, seed, m, k, eq, neg, zr):
 
 
 @gpu
+def test_gpu_corner_shapes(ctx):
+    """One row; every row negated; a maximisation (bounded: negative costs); equality rows only."""
+    cases = []
+    A, b, c, no = lpcases.min_lp(11, 1, 3)
+    cases.append((A, b, c, no, False))
+    A, b, c, no = lpcases.min_lp(12, 6, 5, negative_rows=6)
+    cases.append((A, b, c, no, False))
+    A, b, c, no = lpcases.min_lp(13, 7, 6, equalities=2, negative_rows=3)
+    cases.append((A, b, -c, no, True))            # max -c.x  ==  min c.x
+    A, b, c, no = lpcases.degenerate_eq_lp(14, m=5, k=9, zero_rows=1)
+    cases.append((A, b, c, no, False))
+    for A, b, c, no, mx in cases:
+        r = o.two_phase(A, b, c, maximize=mx, n_orig=no)
+        g = ctx.two_phase(A, b, c, maximize=mx, n_orig=no)
+        assert r["status"] == o.OPTIMAL
+        _same(g, r)
+    # an unbounded phase II: min -x1 with x1 - x2 = 1 (x1 can grow with x2)
+    A = np.array([[1.0, -1.0]])
+    r = o.two_phase(A, [1.0], [-1.0, 0.0], maximize=False, n_orig=2)
+    g = ctx.two_phase(A, [1.0], [-1.0, 0.0], maximize=False, n_orig=2)
+    assert r["status"] == o.UNBOUNDED and g["status"] == o.UNBOUNDED
+
+
+@gpu
 def test_gpu_drive_out_bit_exact(ctx):
     hits = 0
     for seed in range(60):
