@@ -82,3 +82,24 @@ def test_batched_problem_object_and_timing(ctx):
     assert np.array_equal(d1["x"], d2["x"]) and np.array_equal(d1["iters"], d2["iters"])
     _check(d2, A, b, c, basis, True, 32)
     p.free()
+
+
+def test_fuzz_shapes_and_signed_data(ctx):
+    """40 shapes x 12 LPs with signed constraint data (unbounded and degenerate ones among them),
+    both senses, tight iteration limits: the LDS-resident kernel against the oracle, LP by LP."""
+    rng = np.random.default_rng(4242)
+    for trial in range(40):
+        m = int(rng.integers(1, 20))
+        extra = int(rng.integers(1, 24))
+        n = m + extra
+        count = 12
+        A = np.empty((count, m, n)); b = np.empty((count, m)); c = np.empty((count, n))
+        basis = np.tile(np.arange(extra, n, dtype=np.int32), (count, 1))
+        for k in range(count):
+            A[k] = np.hstack([np.round(rng.uniform(-1, 1.5, (m, extra)), 1), np.eye(m)])
+            b[k] = np.round(rng.uniform(0.0, 2.0, m), 1)          # zeros: degenerate vertices
+            c[k] = np.concatenate([np.round(rng.uniform(-1, 1, extra), 1), np.zeros(m)])
+        maximize = bool(rng.integers(0, 2))
+        max_iter = int(rng.choice([1, 3, 10000]))
+        g = ctx.simplex_solve_batched(A, b, c, basis, maximize, n, max_iter=max_iter)
+        _check(g, A, b, c, basis, maximize, n, max_iter=max_iter)

@@ -370,3 +370,27 @@ def test_full_size_properties(ctx, m, n):
     r1, gz, gcounts, _ = p.range(lo, hi)
     assert (r1, gz, gcounts) == (st, oz, ocounts) and gz == z
     p.free()
+
+
+def test_fuzz_small_structured_problems(ctx):
+    """150 small problems with integer data in {-1, 0, 1, 2} (ties, zero pivots, duplicate columns
+    everywhere), both senses: counts, optimum and the tie rule's rank against the oracle — on the
+    direct kernel, and on the shared-prefix kernels where the shape allows."""
+    rng = np.random.default_rng(77)
+    for trial in range(150):
+        m = int(rng.integers(1, 9))
+        n = m + int(rng.integers(1, 7))
+        A = rng.integers(-1, 3, size=(m, n)).astype(np.float64)
+        b = rng.integers(0, 4, size=m).astype(np.float64)
+        c = rng.integers(-2, 3, size=n).astype(np.float64)
+        maximize = bool(rng.integers(0, 2))
+        total = o.binom(n, m)
+        ref = o.enum_range(A, b, c, maximize, 0, total)
+        p = ctx.enum_problem(A, b, c, maximize)
+        algos = [capi.ENUM_DIRECT] + ([capi.ENUM_PREFIX] if 6 <= m <= 16 and 2 <= n - m <= 16 else [])
+        for algo in algos:
+            got = p.range(0, total, algo)[:3]
+            assert got == ref, (trial, m, n, algo)
+            if ref[0] == 0:
+                assert p.first_within(0, total, ref[1]) == o.enum_first_within(A, b, c, maximize, 0, total, ref[1])
+        p.free()

@@ -189,3 +189,28 @@ def test_update_microbenchmarks_and_profiling(ctx):
     rc, st = p.run(algo=capi.SIMPLEX_LOOKAHEAD)
     assert st.update_launches == 0 and st.pivots == r["iters"]
     p.free()
+
+
+def test_fuzz_small_problems(ctx):
+    """200 small random LPs — signed data, both senses, slack and general starting bases, tight
+    iteration limits: status, pivot sequence, basis and vertex bit-exact against the oracle on
+    both device algorithms."""
+    rng = np.random.default_rng(2024)
+    for trial in range(200):
+        m = int(rng.integers(1, 7))
+        extra = int(rng.integers(0, 7))
+        n = m + extra
+        maximize = bool(rng.integers(0, 2))
+        max_iter = int(rng.choice([1, 2, 5, 10000]))
+        if trial % 3 == 0 and extra > 0:
+            A, b, c, basis = lpcases.general_lp(1000 + trial, m, n, signed=True)   # (m+1) x (n+1)
+            n = A.shape[1]
+        else:
+            A = np.hstack([rng.uniform(-1, 1, (m, extra)), np.eye(m)])
+            b = rng.uniform(0.1, 2.0, m)
+            c = np.concatenate([rng.uniform(-1, 1, extra), np.zeros(m)])
+            basis = np.arange(extra, n, dtype=np.int32)
+        r = o.simplex_tableau(A, b, c, basis, maximize, n, max_iter=max_iter, trace_cap=64, want_tableau=True)
+        for algo in ALGOS:
+            g = _run(ctx, A, b, c, basis, maximize, n, trace_cap=64, max_iter=max_iter, algo=algo)
+            _assert_bit_exact(g, r)
