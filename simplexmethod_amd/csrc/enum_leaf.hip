@@ -252,7 +252,9 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
 }
 
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
-constexpr int kItemLanes = 4;  // lanes of k_enum_make_items that share one record
+// lanes of k_enum_make_items that share one record: 4 on wide levels, 8 on the narrow ones of a small
+// rank range (there the kernel's run time is the length of one lane's loop)
+constexpr int kItemLanesWide = 4, kItemLanesNarrow = 8;
 
 // Work items of the leaf kernels, so that no item is longer than 16 wave passes — a depth m-6 node
 // can hold up to C(22,6) = 74,613 subsets, and a rank-range shard of an 8-GPU run is only a few
@@ -272,7 +274,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev pd,
                                                          const double* __restrict__ roots,
                                                          int root_level, int root_cap, int min_child_R,
-                                                         unsigned long long begin,
+                                                         int kItemLanes, unsigned long long begin,
                                                          unsigned long long end) {
     constexpr int KD = 6;
     // C(r, 5) and C(r, 6) for r <= NMX + KD + 1, from LDS (the loops below are chains of dependent
@@ -841,15 +843,16 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
     if (fused) {
-        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * kItemLanes, 1024), 1024, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, THIN_TAIL, b, e);
+        const int lanes = bound < 300000 ? kItemLanesNarrow : kItemLanesWide;
+        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, ctx->stream, p->dev, pd,
+                           roots, level, bound, THIN_TAIL, lanes, b, e);
         hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
         hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
         hipLaunchKernelGGL(k_enum_thin, (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12),
                            LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 1024), 1024, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, 0, b, e);
+                           roots, level, bound, 0, 1, b, e);
         hipLaunchKernelGGL(k_enum_leaves<0>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
     }
     return LP_OPTIMAL;
