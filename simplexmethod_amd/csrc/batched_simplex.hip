@@ -245,6 +245,47 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
     return sel;
 }
 
+// The ratio test (:181-194) by one wave with its K = ceil(m / 64) ratios held in registers (one
+// division per row instead of one per pass of wave_scan_keyed): keys are the basis positions, i.e.
+// the entry index itself.  Returns the leaving position, -1 if no ratio is finite.
+template <int K>
+__device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, double eps) {
+    const int lane = threadIdx.x & 63;
+    double lext = INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) lext = fmin(lext, rv[k]);
+    const double M = lpdev::wave_ext_f64<false>(lext);
+    if (!(M < INFINITY)) return -1;
+    int lidx = INT_MAX;
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) lidx = (rv[k] == M && lane + 64 * k < m) ? lane + 64 * k : lidx;
+    const int jM = lpdev::wave_min_i32(lidx);
+    double lp = INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) lp = (lane + 64 * k < jM) ? fmin(lp, rv[k]) : lp;
+    const double P = lpdev::wave_ext_f64<false>(lp);
+    if (M < P - eps) return jM;
+    // near-tie: replay the chain jump by jump
+    double best = INFINITY;
+    int sel = -1;
+    for (;;) {
+        const double thr = best - eps;
+        int cand = INT_MAX;
+        double cv = INFINITY;
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k)
+            if (rv[k] < thr && lane + 64 * k < m) {
+                cand = lane + 64 * k;
+                cv = rv[k];
+            }
+        const int first = lpdev::wave_min_i32(cand);
+        if (first == INT_MAX) break;
+        best = lpdev::wave_bcast_f64(cv, first & 63);
+        sel = first;
+    }
+    return sel;
+}
+
 __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = d.m, n = d.n, nn = n - m, W = nn + 1, pitch = d.pitch;
@@ -330,18 +371,34 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
         // the ratios with all threads first and scanning an LDS array was measured slower: one more
         // barrier than the divisions cost)
         if (wave == 0) {
-            int any_pos = 0;
-            for (int i = lane; i < m; i += 64)
-                if (!(T[(size_t)i * pitch + se] <= eps)) any_pos = 1;
-            double theta;
-            auto getr = [&](int i, double& v, int& k, bool& ok) {
-                const double ui = T[(size_t)i * pitch + se];
-                v = (ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
-                k = i;
-                ok = true;
-            };
-            int r = wave_scan_keyed<false>(m, eps, theta, getr);
-            if (!__any(any_pos)) r = -1;
+            int r;
+            if (m <= 256) {
+                // up to four rows per lane: ratios computed once, kept in registers
+                double rv[4];
+                int any_pos = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = lane + 64 * k;
+                    const double ui = (i < m) ? T[(size_t)i * pitch + se] : 0.0;
+                    rv[k] = (i < m && ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
+                    if (i < m && !(ui <= eps)) any_pos = 1;
+                }
+                r = wave_ratio_select<4>(rv, m, eps);
+                if (!__any(any_pos)) r = -1;
+            } else {
+                int any_pos = 0;
+                for (int i = lane; i < m; i += 64)
+                    if (!(T[(size_t)i * pitch + se] <= eps)) any_pos = 1;
+                double theta;
+                auto getr = [&](int i, double& v, int& k, bool& ok) {
+                    const double ui = T[(size_t)i * pitch + se];
+                    v = (ui > eps) ? T[(size_t)i * pitch + nn] / ui : INFINITY;
+                    k = i;
+                    ok = true;
+                };
+                r = wave_scan_keyed<false>(m, eps, theta, getr);
+                if (!__any(any_pos)) r = -1;
+            }
             if (lane == 0) pub[1] = r;
         }
         __syncthreads();
