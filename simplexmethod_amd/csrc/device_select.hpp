@@ -106,9 +106,8 @@ __device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
 // selected index or -1; `best` ends as the chain's final value (+-inf if nothing
 // was eligible).  WANT_MAX: the :153-161 form (v > best + eps); otherwise the
 // :164-172 / :181-192 form (v < best - eps).
-template <bool WANT_MAX, typename Load>
+template <bool WANT_MAX, int K = 16, typename Load>   // K: entries per lane per tile (a power of two)
 __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
-    constexpr int K = 16;  // entries per lane per tile
     constexpr int TILE = 64 * K;
     const int lane = threadIdx.x & 63;
     const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
@@ -127,11 +126,16 @@ __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
             val[k] = (ok && j < len) ? v : sentinel;
         }
         auto ext = [](double a, double b) { return WANT_MAX ? fmax(a, b) : fmin(a, b); };
-        auto tree = [&](const double (&x)[K]) {
-            static_assert(K == 16, "tree below is written for 16 entries");
-            const double a0 = ext(x[0], x[1]), a1 = ext(x[2], x[3]), a2 = ext(x[4], x[5]), a3 = ext(x[6], x[7]);
-            const double a4 = ext(x[8], x[9]), a5 = ext(x[10], x[11]), a6 = ext(x[12], x[13]), a7 = ext(x[14], x[15]);
-            return ext(ext(ext(a0, a1), ext(a2, a3)), ext(ext(a4, a5), ext(a6, a7)));
+        auto tree = [&](const double (&x)[K]) {   // balanced: depth log2 K
+            static_assert((K & (K - 1)) == 0, "K must be a power of two");
+            double t[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = x[i];
+#pragma unroll
+            for (int w = K / 2; w >= 1; w /= 2)
+#pragma unroll
+                for (int i = 0; i < w; ++i) t[i] = ext(t[i], t[i + w]);
+            return t[0];
         };
         const double lext = tree(val);  // this lane's extreme value (NaN entries never win: fmax/fmin drop them)
         // ---- fast path

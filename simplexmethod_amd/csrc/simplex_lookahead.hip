@@ -172,7 +172,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
                 ok = true;
                 return s.ratio[i];
             };
-            const int r0 = lpdev::wave_chain_select<false>(m, eps, theta, load);
+            // entries per lane sized to m: a 16-entry tile would scan clamped duplicates for m <= 512
+            const int r0 = (m <= 256)   ? lpdev::wave_chain_select<false, 4>(m, eps, theta, load)
+                           : (m <= 512) ? lpdev::wave_chain_select<false, 8>(m, eps, theta, load)
+                                        : lpdev::wave_chain_select<false, 16>(m, eps, theta, load);
             if (tid == 0) s.sc->sel = r0;
         }
         __syncthreads();
