@@ -98,8 +98,17 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
     const double eps = st->eps;
     const int max_iter = st->max_iter;
     int iters = st->iters;
-    for (int j = tid; j <= n; j += SEL_THREADS) s.d[j] = la.dvec[j];
-    for (int j = tid; j < n; j += SEL_THREADS) s.nb[j] = d.nonbasic[j];
+    // The LDS copy of the reduced-cost row holds the pricing scan's sentinel (-inf / +inf) in the
+    // basic columns instead of their exact zeros: the scan then needs no mask (one LDS read per
+    // entry instead of two and a select).  A basic column's entry is only ever read again when its
+    // variable leaves the basis, where its reduced cost is known to be 0.
+    const double d_sentinel = d.maximize ? -INFINITY : INFINITY;
+    for (int j = tid; j < n; j += SEL_THREADS) {
+        const unsigned char nbj = d.nonbasic[j];
+        s.nb[j] = nbj;
+        s.d[j] = nbj ? la.dvec[j] : d_sentinel;
+    }
+    if (tid == 0) s.d[n] = la.dvec[n];
     for (int i = tid; i < m; i += SEL_THREADS) {
         s.rhs[i] = la.rhs[i];
         s.basis[i] = d.basis[i];
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         if (tid < 64) {
             double best;
             auto load = [&](int j, bool& ok) {
-                ok = s.nb[j] != 0;  // complement(), :97-108
+                ok = true;          // basic columns hold the sentinel (complement(), :97-108)
                 return s.d[j];
             };
             int e0 = d.maximize ? lpdev::wave_chain_select<true>(n, eps, best, load)
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         double* prS = s.prH + (size_t)sidx * (n + 1);
         double* etaP = la.etaP + (size_t)sidx * ld;
         const double t_first = (tid < n) ? T[(size_t)r * ld + tid] : 0.0;
+        const int oldb = s.basis[r];   // leaves the basis with this pivot
         // ---- eta column (:198-204) + xB update
         double* lcS = s.lcH + (size_t)sidx * m;
         double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
@@ -217,8 +227,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
             }
             prS[j] = t;
             etaP[j] = t;
-            const double dj = fma(lm, t, s.d[j]);
-            s.d[j] = (j == e) ? 0.0 : dj;
+            const double dj = fma(lm, t, (j == oldb) ? 0.0 : s.d[j]);   // (the leaving variable's was 0)
+            s.d[j] = (j == e) ? d_sentinel : dj;                          // (e becomes basic)
         }
         LP_STAMP(5);
         if (tid == 0) {
