@@ -87,8 +87,12 @@ typedef struct lp_simplex_problem lp_simplex_problem;
 enum {
     LP_SIMPLEX_ALGO_AUTO = 0,
     LP_SIMPLEX_ALGO_LAUNCH = 1,    /* one select + one rank-1-update launch per pivot   */
-    LP_SIMPLEX_ALGO_LOOKAHEAD = 2  /* J pivots staged by a one-workgroup selector, then
+    LP_SIMPLEX_ALGO_LOOKAHEAD = 2, /* J pivots staged by a one-workgroup selector, then
                                       one rank-J update pass over the tableau            */
+    LP_SIMPLEX_ALGO_RESIDENT = 3   /* one launch per solve: the tableau stays in the registers of
+                                      ceil(n/32) co-resident workgroups (m <= 1024, n <= 8192),
+                                      one all-to-all hand-off per pivot; AUTO's choice when the
+                                      shape fits                                          */
 };
 
 typedef struct lp_simplex_stats {

@@ -127,6 +127,7 @@ void lp_simplex_free(lp_simplex_problem* p) {
     (void)hipFree(p->look.etaL); (void)hipFree(p->look.etaP); (void)hipFree(p->look.dvec);
     (void)hipFree(p->look.rhs); (void)hipFree(p->look.piv); (void)hipFree(p->look.count);
     (void)hipFree(p->look.stamps);
+    (void)hipFree(p->res.comm); (void)hipFree(p->res.stamps);
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -194,6 +195,8 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
         LP_TRY(hipMalloc(&la.count, sizeof(int)));
         LP_TRY(hipMemsetAsync(la.count, 0, sizeof(int), ctx->stream));
     }
+
+    if (lp_resident_plan(m, n, &p->res)) LP_TRY(hipMalloc(&p->res.comm, p->res.comm_bytes));
 
     // Initial tableau [A | b] with the cost row c underneath, row-major (host-side O(mn)
     // layout change: Eigen's column-major A -> rows that the update kernel streams).
@@ -276,8 +279,13 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
         return p->init_status;
     }
     if (algo == LP_SIMPLEX_ALGO_AUTO)
-        algo = p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD : LP_SIMPLEX_ALGO_LAUNCH;
+        algo = p->res.G >= 1 ? LP_SIMPLEX_ALGO_RESIDENT
+                             : (p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD : LP_SIMPLEX_ALGO_LAUNCH);
     switch (algo) {
+        case LP_SIMPLEX_ALGO_RESIDENT:
+            if (p->res.G < 1)
+                LP_FAIL(ctx, LP_BAD_ARG, "chip-resident simplex needs m <= 1024 and n <= 8192");
+            return lp_simplex_run_resident(p, eps, max_iter, stats_out);
         case LP_SIMPLEX_ALGO_LAUNCH:
             return lp_simplex_run_launch(p, eps, max_iter, stats_out);
         case LP_SIMPLEX_ALGO_LOOKAHEAD: {
@@ -460,13 +468,20 @@ int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long
     LP_HIP(ctx, hipSetDevice(ctx->device));
     if (!p->look.stamps) {
         if (cap_pivots <= 0) return LP_OPTIMAL;
-        LP_HIP(ctx, hipMalloc(&p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64)));
-        LP_HIP(ctx, hipMemset(p->look.stamps, 0, sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64)));
+        const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64);
+        LP_HIP(ctx, hipMalloc(&p->look.stamps, bytes));
+        LP_HIP(ctx, hipMemset(p->look.stamps, 0, bytes));
+        const size_t rbytes = sizeof(unsigned long long) * 8 * 4096;   // the resident kernel stamps 4096 pivots
+        LP_HIP(ctx, hipMalloc(&p->res.stamps, rbytes));
+        LP_HIP(ctx, hipMemset(p->res.stamps, 0, rbytes));
         return LP_OPTIMAL;
     }
-    if (out)
-        LP_HIP(ctx, hipMemcpy(out, p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)cap_pivots,
-                              hipMemcpyDeviceToHost));
+    if (out) {
+        const bool res = p->last_algo == LP_SIMPLEX_ALGO_RESIDENT;
+        if (res && cap_pivots > 4096) cap_pivots = 4096;
+        LP_HIP(ctx, hipMemcpy(out, res ? p->res.stamps : p->look.stamps,
+                              sizeof(unsigned long long) * 8 * (size_t)cap_pivots, hipMemcpyDeviceToHost));
+    }
     return LP_OPTIMAL;
 }
 

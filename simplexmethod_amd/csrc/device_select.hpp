@@ -179,104 +179,130 @@ __device__ int wave_chain_select(int len, double eps, double& best, Load load) {
 }
 
 // ---------------------------------------------------------------------------
-// Workgroup-wide form of the same scan for values that already sit in LDS.
-// Every thread of the block must call it (it contains barriers).  Thread t owns
-// the KT = ceil(len/NT) consecutive entries [t*KT, t*KT+KT), so (wave, lane) order
-// is index order.  Stage 1: every wave reduces its slice to (M_w, first index j_w,
-// P_w = maximum of the wave's entries before j_w).  Stage 2: wave 0 combines the
-// <= 16 slices: global M, the first wave w* attaining it, P = max(M_w for w < w*,
-// P_w*).  If M > P + eps the answer is (M, j_w*) as in wave_chain_select's fast
-// path; otherwise wave 0 replays the whole chain (slow path).
+// Reductions on SORTABLE KEYS.  A double maps to a 64-bit key whose unsigned order is the numeric
+// order (-inf lowest, +inf highest; the caller replaces NaNs by its sentinel first), and a wave
+// extreme of keys is two passes of six 32-bit DPP min/max instructions (high words, then low
+// words among the lanes that tie on the high word): v_max_u32 / v_min_u32 take the DPP operand
+// directly, where an fp64 extreme needs two DPP moves and a v_max_f64 per step — less than half
+// the dependent latency, which is all a lone reducing wave pays.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long f64_sort_key(double v) {
+    const long long b = __double_as_longlong(v);
+    return (unsigned long long)(b ^ ((b >> 63) | (long long)0x8000000000000000ull));
+}
+__device__ __forceinline__ double f64_from_key(unsigned long long k) {
+    const long long b = (long long)k;
+    return __longlong_as_double((b < 0) ? (b ^ (long long)0x8000000000000000ull) : ~b);
+}
+
+// Extreme of a 32-bit unsigned value over the 64 lanes (all lanes must be active); uniform result.
+// One asm block: the DPP hazard (a VALU write followed by a DPP read of the same VGPR needs two
+// wait states) is covered by the s_nop 1 between steps.
+template <bool WANT_MAX>
+__device__ __forceinline__ unsigned wave_ext_u32(unsigned v) {
+    if (WANT_MAX) {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+            : "+v"(v));
+    } else {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+            : "+v"(v));
+    }
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <bool WANT_MAX>
+__device__ __forceinline__ unsigned long long wave_ext_key(unsigned long long key) {
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned mhi = wave_ext_u32<WANT_MAX>(hi);
+    const unsigned lo2 = (hi == mhi) ? lo : (WANT_MAX ? 0u : 0xFFFFFFFFu);
+    const unsigned mlo = wave_ext_u32<WANT_MAX>(lo2);
+    return ((unsigned long long)mhi << 32) | mlo;
+}
+
+__device__ __forceinline__ unsigned long long wave_bcast_u64(unsigned long long v, int src_lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// Workgroup-wide form of the chain scan, ONE entry per thread: thread t holds entry t in `v`
+// (threads past the end and ineligible entries hold the sentinel, NaNs replaced by it) and has
+// also written it to vals[t] in LDS (read only by the slow path).
+//   block_select_stage1: every wave reduces its 64 entries to (M_w, first index j_w, P_w = extreme
+//     of the wave's entries before j_w) and stores them in LDS.  The caller then executes a
+//     workgroup barrier.
+//   block_select_stage2: ONE full wave (any) combines the <= 16 slices: global M, the first wave
+//     w* attaining it, P = ext(M_w for w < w*, P_w*).  If M beats P by more than eps the answer is
+//     (M, j_w*) as in wave_chain_select's fast path; otherwise that wave replays the whole chain.
 // ---------------------------------------------------------------------------
 struct BlockSelScratch {  // 16-B aligned, lives in LDS
-    double M[16];
-    double P[16];
+    unsigned long long M[16];   // sortable keys
+    unsigned long long P[16];
     int J[16];
-    double best;
-    int sel;
-    int pad;
 };
+
+template <bool WANT_MAX>
+__device__ __forceinline__ void block_select_stage1(double v, BlockSelScratch* sc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long skey = f64_sort_key(WANT_MAX ? -INFINITY : INFINITY);
+    const unsigned long long key = f64_sort_key(v);
+    const unsigned long long mk = wave_ext_key<WANT_MAX>(key);
+    const unsigned long long hit = __ballot(key == mk && key != skey);
+    const int L = hit ? (int)__builtin_ctzll(hit) : 64;
+    const unsigned long long pk = wave_ext_key<WANT_MAX>(lane < L ? key : skey);
+    if (lane == 0) {
+        sc->M[wave] = hit ? mk : skey;
+        sc->P[wave] = hit ? pk : skey;
+        sc->J[wave] = hit ? wave * 64 + L : INT_MAX;
+    }
+}
+
+template <bool WANT_MAX>
+__device__ __forceinline__ int block_select_stage2(const double* vals, int len, double eps,
+                                                   const BlockSelScratch* sc) {
+    const int lane = threadIdx.x & 63, nwaves = (int)(blockDim.x >> 6);
+    const unsigned long long skey = f64_sort_key(WANT_MAX ? -INFINITY : INFINITY);
+    const bool has = lane < nwaves;
+    const unsigned long long Ml = has ? sc->M[lane] : skey;
+    const unsigned long long Pl = has ? sc->P[lane] : skey;
+    const int Jl = has ? sc->J[lane] : INT_MAX;
+    const unsigned long long M = wave_ext_key<WANT_MAX>(Ml);
+    const unsigned long long whit = __ballot(has && Ml == M && Jl != INT_MAX);
+    if (!whit) return -1;
+    const int W = (int)__builtin_ctzll(whit);
+    const int jM = __builtin_amdgcn_readlane(Jl, W);
+    const unsigned long long Pin = wave_bcast_u64(Pl, W);
+    const unsigned long long Pprev = wave_ext_key<WANT_MAX>((lane < W) ? Ml : skey);
+    const unsigned long long Pk = WANT_MAX ? (Pprev > Pin ? Pprev : Pin) : (Pprev < Pin ? Pprev : Pin);
+    const double Md = f64_from_key(M), Pd = f64_from_key(Pk);
+    if (WANT_MAX ? (Md > Pd + eps) : (Md < Pd - eps)) return jM;
+    double best;   // near-tie: exact replay over the LDS copy
+    auto load = [&](int j, bool& ok) {
+        ok = true;
+        return vals[j];
+    };
+    return wave_chain_select<WANT_MAX>(len, eps, best, load);
+}
 
 template <bool WANT_MAX>
 __device__ __forceinline__ double ext2(double a, double b) {
     return WANT_MAX ? (a > b ? a : b) : (a < b ? a : b);
-}
-
-template <bool WANT_MAX>
-__device__ int block_chain_select(const double* vals, const unsigned char* mask, int len,
-                                  double eps, double& best_out, BlockSelScratch* sc) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
-    const int KT = (len + nt - 1) / nt;
-    double lv = sentinel, lp = sentinel;  // thread extreme, extreme of its entries before it
-    int lj = INT_MAX;
-    for (int k = 0; k < KT; ++k) {
-        const int j = tid * KT + k;
-        const int jc = j < len ? j : len - 1;
-        double v = vals[jc];
-        const bool ok = (j < len) && (mask == nullptr || mask[jc] != 0);
-        v = ok ? v : sentinel;
-        if (WANT_MAX ? (v > lv) : (v < lv)) {
-            lp = lv;  // everything seen so far precedes the new extreme
-            lv = v;
-            lj = j;
-        } else {
-            // entries after the extreme do not matter for P
-        }
-    }
-    // stage 1: this wave's slice
-    const double Mw = wave_ext_f64<WANT_MAX>(lv);
-    const unsigned long long hit = __ballot(lv == Mw && lj != INT_MAX);
-    int L = hit ? (int)__builtin_ctzll(hit) : 0;
-    const int jw = hit ? __builtin_amdgcn_readlane(lj, L) : INT_MAX;
-    const double contrib = (lane < L) ? lv : ((lane == L) ? lp : sentinel);
-    const double Pw = wave_ext_f64<WANT_MAX>(hit ? contrib : sentinel);
-    if (lane == 0) {
-        sc->M[wave] = Mw;
-        sc->P[wave] = Pw;
-        sc->J[wave] = jw;
-    }
-    __syncthreads();
-    // stage 2: wave 0 combines the slices
-    if (wave == 0) {
-        const bool has = lane < nwaves;
-        const double Ml = has ? sc->M[lane] : sentinel;
-        const double Pl = has ? sc->P[lane] : sentinel;
-        const int Jl = has ? sc->J[lane] : INT_MAX;
-        const double M = wave_bcast_f64(row16_ext_f64<WANT_MAX>(Ml), 0);
-        const unsigned long long whit = __ballot(has && Ml == M && Jl != INT_MAX);
-        int sel = -1;
-        double best = sentinel;
-        bool slow = false;
-        if (whit) {
-            const int W = (int)__builtin_ctzll(whit);
-            const int jM = __builtin_amdgcn_readlane(Jl, W);
-            const double Pin = wave_bcast_f64(Pl, W);
-            const double Pprev = wave_bcast_f64(row16_ext_f64<WANT_MAX>((lane < W) ? Ml : sentinel), 0);
-            const double P = ext2<WANT_MAX>(Pprev, Pin);
-            if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
-                best = M;
-                sel = jM;
-            } else {
-                slow = true;
-            }
-        }
-        if (slow) {
-            auto load = [&](int j, bool& ok) {
-                ok = (mask == nullptr) || mask[j] != 0;
-                return vals[j];
-            };
-            sel = wave_chain_select<WANT_MAX>(len, eps, best, load);
-        }
-        if (lane == 0) {
-            sc->best = best;
-            sc->sel = sel;
-        }
-    }
-    __syncthreads();
-    best_out = sc->best;
-    return sc->sel;
 }
 
 }  // namespace lpdev

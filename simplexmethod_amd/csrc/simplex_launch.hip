@@ -444,6 +444,7 @@ int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_si
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->last_status = status;
+    p->last_algo = LP_SIMPLEX_ALGO_LAUNCH;
     p->last_iters = p->h_state->iters;
     if (stats) {
         stats->status = status;

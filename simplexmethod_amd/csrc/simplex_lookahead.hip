@@ -38,10 +38,14 @@ struct QInfo {   // one staged pivot, read with a single 16-B LDS load
     int eq;      // entering column
 };
 
-constexpr int kScratchDoubles = (int)(sizeof(lpdev::BlockSelScratch) / 8);
+struct SelScratch {  // what the scanning wave hands to the rest of the workgroup
+    int sel;
+    int pad[3];
+};
+constexpr int kScratchDoubles = (int)(sizeof(SelScratch) / 8);
 
 struct SelLds {
-    lpdev::BlockSelScratch* sc;  // chain-select scratch (16-B aligned, first)
+    SelScratch* sc;  // selected index of the last scan (16-B aligned, first)
     QInfo* qi;      // J   : staged pivots (16-B aligned)
     double* d;      // n+1 : reduced-cost row (entry n = -objective)
     double* rhs;    // m   : xB
@@ -68,7 +72,7 @@ __host__ __device__ inline size_t sel_lds_bytes(int m, int n, int J) {
 
 __device__ inline SelLds carve(double* base, int m, int n, int J) {
     SelLds s;
-    s.sc = reinterpret_cast<lpdev::BlockSelScratch*>(base);
+    s.sc = reinterpret_cast<SelScratch*>(base);
     s.qi = reinterpret_cast<QInfo*>(base + kScratchDoubles);
     s.d = base + kScratchDoubles + 2 * (size_t)J;
     s.rhs = s.d + (n + 1);
@@ -198,13 +202,13 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
         const double inv = 1.0 / ur;       // F(r,r), :204
         const double lm = -s.d[e] / ur;    // F row of the reduced costs
         const double rhs_r = s.rhs[r];
-        __syncthreads();                   // everyone has read d[e], rhs[r] before they change
+        const int oldb = s.basis[r];       // leaves the basis with this pivot (read before thread 0 rewrites it)
+        __syncthreads();                   // everyone has read d[e], rhs[r], basis[r] before they change
         // ---- pivot row of the CURRENT tableau (before scaling) + reduced-cost update.  The stale
         // row's HBM read is issued first and the eta column + xB update (LDS only) run under it.
         double* prS = s.prH + (size_t)sidx * (n + 1);
         double* etaP = la.etaP + (size_t)sidx * ld;
         const double t_first = (tid < n) ? T[(size_t)r * ld + tid] : 0.0;
-        const int oldb = s.basis[r];   // leaves the basis with this pivot
         // ---- eta column (:198-204) + xB update
         double* lcS = s.lcH + (size_t)sidx * m;
         double* etaL = la.etaL + (size_t)sidx * la.rows_pad;
@@ -243,10 +247,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_look_select(SimplexDev d, LookD
             s.qi[sidx] = qi;
             la.piv[2 * sidx] = e;
             la.piv[2 * sidx + 1] = r;
-            const int old = s.basis[r];
             s.basis[r] = e;  // :196
             s.nb[e] = 0;
-            s.nb[old] = 1;
+            s.nb[oldb] = 1;
             if (iters < d.trace_cap) {
                 d.trace_enter[iters] = e;
                 d.trace_leave[iters] = r;
@@ -439,6 +442,7 @@ int lp_simplex_run_lookahead(lp_simplex_problem* p, double eps, int max_iter,
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->last_status = status;
+    p->last_algo = LP_SIMPLEX_ALGO_LOOKAHEAD;
     p->last_iters = p->h_state->iters;
     if (stats) {
         stats->status = status;

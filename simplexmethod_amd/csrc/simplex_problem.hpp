@@ -45,10 +45,24 @@ struct LookDev {
     unsigned long long* stamps;  // diagnostic: 8 s_memtime stamps per pivot (nullptr = off)
 };
 
+// Chip-resident solve (simplex_resident.hip): the tableau lives in the registers of G co-resident
+// workgroups (RS_CPT columns each) for the whole solve; per pivot they exchange one 64-byte record
+// and one entering column each through these buffers (8-byte {epoch tag, value} granules).
+struct ResidentDev {
+    int G;          // participating workgroups = ceil(n / columns per workgroup)
+    int stride;     // participants are the blocks b with b % stride == 0 (8: one XCD under round-robin dispatch)
+    int mpad;       // threads per workgroup = m rounded up to 64 (one tableau row per thread)
+    int pad0;
+    char* comm;     // one allocation, zeroed before every launch; carved below (byte offsets)
+    unsigned recA_off, recB_off, col_off, dpub_off, recS_off, colS_off, census_off, abort_off, comm_bytes;
+    unsigned long long* stamps;  // diagnostic: 8 cycle stamps per pivot from workgroup 0 (nullptr = off)
+};
+
 struct lp_simplex_problem {
     lp_context* ctx = nullptr;
     SimplexDev dev{};
     LookDev look{};
+    ResidentDev res{};            // res.G == 0: shape outside the chip-resident path
     int n_orig = 0;
     size_t tableau_bytes = 0;
     double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset
@@ -64,6 +78,7 @@ struct lp_simplex_problem {
     int init_status = LP_OPTIMAL; // LP_SINGULAR if the initial basis was singular
     int last_status = -100;
     int last_iters = 0;
+    int last_algo = 0;            // LP_SIMPLEX_ALGO_* of the last run (which stamp buffer is current)
 };
 
 // simplex_launch.hip
@@ -74,6 +89,10 @@ int lp_simplex_force(lp_simplex_problem* p, int row, int col);  // host-chosen p
 int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
 int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, float* ms_out);
+
+// simplex_resident.hip
+int lp_resident_plan(int m, int n, ResidentDev* out);   // fills G/stride/mpad/offsets; 0 if the shape does not fit
+int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 
 // simplex_lookahead.hip
 int lp_lookahead_pick_j(int m, int n);

@@ -151,7 +151,7 @@ std::unique_ptr<Symmetrical> Symmetrical::GetDual() const {
 std::unique_ptr<Canonical> Symmetrical::ToCanonical() const {
     const long m = A_.rows(), n = A_.cols();
     const long extra = maximize_ ? m : 2 * m;
-    MatrixXd Ac(m, n + extra);
+    MatrixXd Ac = MatrixXd::Zero(m, n + extra);   // Eigen's sized ctor leaves memory uninitialised (Symmetrical.cpp:166-173 uses Zero/Identity blocks)
     VectorXd cc = VectorXd::Zero(n + extra);
     for (long j = 0; j < n; ++j) {
         cc[j] = c_[j];
@@ -242,7 +242,7 @@ std::unique_ptr<Symmetrical> Canonical::ToSymmetrical() const {
 
 std::unique_ptr<Canonical> Canonical::GetDual() const {
     const long m = A_.rows(), n = A_.cols();
-    MatrixXd Ad(n, 2 * m + n);
+    MatrixXd Ad = MatrixXd::Zero(n, 2 * m + n);
     VectorXd cd = VectorXd::Zero(2 * m + n);
     for (long i = 0; i < m; ++i) {
         cd[i] = b_[i];          // y'

@@ -30,12 +30,22 @@ for seed, m, n in [(0, 4, 9), (1, 8, 16), (2, 16, 32), (3, 32, 64), (4, 64, 128)
     assert r["status"] == 0
     ref = linprog(-c[:n - m], A_ub=A[:, :n - m], b_ub=b, bounds=(0, None), method="highs")
     assert ref.status == 0 and abs(r["obj"] + ref.fun) <= 1e-9 * abs(ref.fun), (seed, m, n)
-    if m <= 128:
-        rr = o.simplex_reference(A, b, c, basis, True, n - m, trace_cap=1 << 14)
-        assert rr["trace"] == r["trace"] and np.allclose(rr["x"], r["x"], rtol=1e-10, atol=1e-12)
-    simplex.append(dict(seed=seed, m=m, n=n, iters=r["iters"], basis=r["basis"].tolist(),
-                        obj=r["obj"], trace_head=r["trace"][:16],
-                        x_nonzero={str(j): v for j, v in enumerate(r["x"].tolist()) if v != 0.0}))
+    # the reference-SHAPED restatement (Binv recomputed by full-pivot LU every iteration,
+    # /root/reference/src/SimplexSolover.h:429-447): ~20 s at 512 x 1024, run once here
+    rr = o.simplex_reference(A, b, c, basis, True, n - m, trace_cap=1 << 14)
+    assert rr["status"] == 0 and rr["trace"] == r["trace"] and np.array_equal(rr["basis"], r["basis"])
+    assert np.allclose(rr["x"], r["x"], rtol=1e-10, atol=1e-12)
+    assert abs(rr["obj"] - r["obj"]) <= 1e-10 * abs(r["obj"])
+    case = dict(seed=seed, m=m, n=n, iters=r["iters"], basis=r["basis"].tolist(),
+                obj=r["obj"], trace_head=r["trace"][:16],
+                x_nonzero={str(j): v for j, v in enumerate(r["x"].tolist()) if v != 0.0})
+    # outputs of the reference-shaped form: what the GPU is held to within the north star's
+    # 1e-10 (trace and basis exactly)
+    case["reference_shaped"] = dict(
+        iters=rr["iters"], basis=rr["basis"].tolist(), obj=rr["obj"],
+        trace=[list(t) for t in rr["trace"]],
+        x_nonzero={str(j): v for j, v in enumerate(rr["x"].tolist()) if v != 0.0})
+    simplex.append(case)
 json.dump(simplex, open(os.path.join(HERE, "simplex_cases.json"), "w"), indent=1)
 
 enum = []

@@ -372,6 +372,50 @@ def test_full_size_properties(ctx, m, n):
     p.free()
 
 
+@pytest.mark.parametrize("m,n", [(14, 28), (16, 32)])   # configs[2], configs[3]
+def test_vertices_against_the_reference_pinned_qr_solve(ctx, m, n):
+    """The GPU's per-subset arithmetic (Gauss-Jordan + 2x2 block, build-defined) against the ONE
+    per-basis solve the reference pins with a fixture of its own: Canonical::GetBasicSolution's
+    ColPivHouseholderQR (/root/reference/src/ProblemTypes/Canonical.cpp:179-197, fixture
+    /root/reference/tests/test_canonical.cpp:41-66 -> oracle orc_basic_solution, checked in
+    tests/test_oracle.py::test_reference_fixture_basic_solution).  The winning vertex and ~1000
+    feasible ranks spread over the whole rank space (first feasible rank of each of 1000 equal
+    windows): every coordinate within the north star's 1e-10 relative, objective likewise, and the
+    reference's feasibility test (IsFeasibleBasis, Canonical.cpp:165-177) agrees."""
+    A, b, c, _ = lpcases.random_lp(0, m, n)
+    p = ctx.enum_problem(A, b, c, True)
+    total = p.total
+    rc, z, counts, _ = p.range(0, total)
+    assert rc == 0
+    ranks = [p.first_within(0, total, z)]
+    windows = 1000
+    W = total // windows
+    none = 2 ** 64 - 1
+    for i in range(windows):
+        r = p.first_within(i * W, (i + 1) * W if i + 1 < windows else total, -np.inf)
+        if r != none:
+            ranks.append(r)
+    assert len(ranks) > min(windows, counts[0]) // 3      # feasible bases are spread out
+    worst = 0.0
+    for r in ranks:
+        v = p.vertex(r, n)
+        assert v["verdict"] == capi.SUBSET_FEASIBLE
+        basis = v["basis"]
+        assert o.rank_of(n, basis) == r
+        st, xq = o.basic_solution(A, b, basis)
+        assert st == 0 and o.is_feasible_basis(A, b, basis)
+        scale = np.abs(xq).max()
+        err = np.abs(v["x"] - xq).max() / scale
+        worst = max(worst, err)
+        assert err <= 1e-10, (r, err)
+        zq = o.evaluate(c, xq)
+        assert abs(v["obj"] - zq) <= 1e-10 * abs(zq), (r, v["obj"], zq)
+    # the winner is the best of the sampled vertices under the QR path too
+    zs = [o.evaluate(c, o.basic_solution(A, b, p.vertex(r, n)["basis"])[1]) for r in ranks[:50]]
+    assert max(zs) <= zs[0] + 1e-9
+    p.free()
+
+
 def test_fuzz_small_structured_problems(ctx):
     """150 small problems with integer data in {-1, 0, 1, 2} (ties, zero pivots, duplicate columns
     everywhere), both senses: counts, optimum and the tie rule's rank against the oracle — on the

@@ -10,7 +10,7 @@ from tests import lpcases
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = [capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD]
+ALGOS = [capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD, capi.SIMPLEX_RESIDENT]
 
 
 def _run(ctx, A, b, c, basis, maximize, n_orig, trace_cap=1 << 14, max_iter=capi.MAX_ITER,
@@ -168,6 +168,34 @@ def test_golden_vectors_gpu(ctx):
         assert g["basis"].tolist() == case["basis"] and g["obj"] == case["obj"]
         for j, v in case["x_nonzero"].items():
             assert g["x"][int(j)] == v
+
+
+def test_config1_against_reference_shaped_golden(ctx):
+    """BASELINE configs[1] (m=512, n=1024, seed 0) against the committed outputs of the
+    reference-SHAPED restatement (Binv recomputed by full-pivot LU every iteration,
+    /root/reference/src/SimplexSolover.h:429-447; generated once by tests/golden/make_golden.py,
+    ~20 s of CPU): pivot trace and basis exactly, vertex and objective within the north star's
+    1e-10 relative — on every device algorithm."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "simplex_cases.json")
+    case = [c for c in json.load(open(path)) if (c["m"], c["n"]) == (512, 1024)][0]
+    ref = case["reference_shaped"]
+    A, b, c, basis = lpcases.random_lp(case["seed"], 512, 1024)
+    xref = np.zeros(512)
+    for j, v in ref["x_nonzero"].items():
+        xref[int(j)] = v
+    for algo in ALGOS + [capi.SIMPLEX_AUTO]:
+        g = _run(ctx, A, b, c, basis, True, 512, algo=algo)
+        assert g["status"] == 0 and g["iters"] == ref["iters"] == 345
+        trace = [list(t) for t in zip(g["trace_enter"][:345].tolist(), g["trace_leave"][:345].tolist())]
+        assert trace == ref["trace"]
+        assert g["basis"].tolist() == ref["basis"]
+        assert abs(g["obj"] - ref["obj"]) <= 1e-10 * abs(ref["obj"])
+        scale = np.abs(xref).max()
+        assert np.abs(g["x"] - xref).max() <= 1e-10 * scale
+        nz = xref != 0
+        assert (np.abs(g["x"][nz] - xref[nz]) <= 1e-10 * np.abs(xref[nz]) + 1e-14 * scale).all()
 
 
 def test_update_microbenchmarks_and_profiling(ctx):

@@ -182,6 +182,14 @@ def test_golden_vectors():
         assert [list(t) for t in r["trace"][:16]] == case["trace_head"]
         for j, v in case["x_nonzero"].items():
             assert r["x"][int(j)] == v
+        # the tableau form (what the GPU executes) against the committed outputs of the
+        # reference-shaped form (SimplexSolover.h:429-447), including 512 x 1024: same pivot
+        # trace and basis, vertex / objective within 1e-10 relative
+        ref = case["reference_shaped"]
+        assert [list(t) for t in r["trace"]] == ref["trace"] and r["basis"].tolist() == ref["basis"]
+        assert abs(r["obj"] - ref["obj"]) <= 1e-10 * abs(ref["obj"])
+        for j, v in ref["x_nonzero"].items():
+            assert abs(r["x"][int(j)] - v) <= 1e-10 * abs(v) + 1e-13
     enum = json.load(open(os.path.join(GOLDEN, "enum_cases.json")))
     for case in enum["random"]:
         A, b, c, _ = lpcases.random_lp(case["seed"], case["m"], case["n"])
