@@ -157,8 +157,10 @@ int lp_bench_rankj_update(lp_simplex_problem* p, int iters, float* ms_per_launch
                           int* pivots_per_launch_out);
 
 /* Diagnostic (not part of the drop-in surface): first call with cap_pivots > 0 turns the
- * look-ahead selector's per-phase cycle stamps on; a later call copies 8 stamps per pivot
- * (s_memtime ticks) for the first cap_pivots pivots of the last run into `out`.         */
+ * selectors' per-phase cycle stamps on; a later call copies the stamps (s_memtime ticks) of the
+ * last run into `out`: after a look-ahead run 8 per pivot for the first cap_pivots pivots; after a
+ * chip-resident run 16 per-phase cycle sums over the solve for each of the first cap_pivots (<= 256)
+ * workgroups.                                                                              */
 int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long long* out);
 
 /* Batched simplex (BASELINE.json configs[4]): `batch` independent LPs of one

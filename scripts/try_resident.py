@@ -47,16 +47,19 @@ for algo, name in [(capi.SIMPLEX_RESIDENT, "resident"), (capi.SIMPLEX_LOOKAHEAD,
 ctx.lib.lp_debug_simplex_stamps(p.h, 400, None)
 p.reset()
 rc, st = p.run(algo=capi.SIMPLEX_RESIDENT)
-buf = (C.c_ulonglong * (8 * 400))()
-ctx.lib.lp_debug_simplex_stamps(p.h, min(400, st.pivots), buf)
-s = np.array(buf[:8 * min(400, st.pivots)], dtype=np.int64).reshape(-1, 8)[5:340]
-names = ["pricing+stage(ratio)", "record P+store", "poll+decide", "barrier B1", "column load", "prow barrier", "update"]
-d = np.diff(s[:, :7], axis=1)
-tot = (s[1:, 0] - s[:-1, 0])
-print("cycles per pivot (median): total %d" % np.median(tot))
-for i in range(6):
-    print("  %-22s %6d" % (names[i], np.median(d[:, i])))
-print("  %-22s %6d" % ("update->next", np.median(s[1:, 0] - s[:-1, 6])))
+G = 32
+buf = (C.c_ulonglong * (16 * G))()
+ctx.lib.lp_debug_simplex_stamps(p.h, G, buf)
+acc = np.array(buf[:16 * G], dtype=np.float64).reshape(G, 16) / st.pivots
+names = ["loop", "poll record A", "decide (+ record B)", "decision barrier",
+         "read decision, pivot row -> LDS, request column, 2 quotients", "pivot-row barrier",
+         "reduced costs + next pricing", "column wait, eta entry", "candidate, publish, ratio stage 1",
+         "ratio barrier", "(wave W2: stage 2 + record B), prefetch", "rank-1 update of 32 columns"]
+print("stamped run: %.3f ms; cycles per pivot (mean over %d pivots), workgroup 0: total %d" % (st.solve_ms, st.pivots, acc[0, :12].sum()))
+for i in range(12):
+    print("  %-62s %6d   (min %5d  max %5d over workgroups)" % (names[i], acc[0, i], acc[:, i].min(), acc[:, i].max()))
+print("poll-A wait per workgroup:", " ".join("%d" % v for v in acc[:, 1]))
+print("decide per workgroup:     ", " ".join("%d" % v for v in acc[:, 2]))
 p.free()
 ctx.close()
 print("ALL OK" if ok else "MISMATCH")

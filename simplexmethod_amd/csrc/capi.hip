@@ -471,16 +471,18 @@ int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long
         const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64);
         LP_HIP(ctx, hipMalloc(&p->look.stamps, bytes));
         LP_HIP(ctx, hipMemset(p->look.stamps, 0, bytes));
-        const size_t rbytes = sizeof(unsigned long long) * 8 * 4096;   // the resident kernel stamps 4096 pivots
+        const size_t rbytes = sizeof(unsigned long long) * 16 * 256;   // the resident kernel: 16 per-phase cycle sums per workgroup
         LP_HIP(ctx, hipMalloc(&p->res.stamps, rbytes));
         LP_HIP(ctx, hipMemset(p->res.stamps, 0, rbytes));
         return LP_OPTIMAL;
     }
     if (out) {
-        const bool res = p->last_algo == LP_SIMPLEX_ALGO_RESIDENT;
-        if (res && cap_pivots > 4096) cap_pivots = 4096;
-        LP_HIP(ctx, hipMemcpy(out, res ? p->res.stamps : p->look.stamps,
-                              sizeof(unsigned long long) * 8 * (size_t)cap_pivots, hipMemcpyDeviceToHost));
+        if (p->last_algo == LP_SIMPLEX_ALGO_RESIDENT)
+            LP_HIP(ctx, hipMemcpy(out, p->res.stamps, sizeof(unsigned long long) * 16 * (size_t)(cap_pivots < 256 ? cap_pivots : 256),
+                                  hipMemcpyDeviceToHost));   // cap_pivots = workgroups wanted here
+        else
+            LP_HIP(ctx, hipMemcpy(out, p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)cap_pivots,
+                                  hipMemcpyDeviceToHost));
     }
     return LP_OPTIMAL;
 }

@@ -49,6 +49,7 @@ struct Ctl {   // decision of the current pivot, written by wave 0, read by ever
     int mode, kst, e, r;
     int oldb, fail, plain, pad;
     double ur, dE;
+    double inv, lm;   // 1/u_r and -T[m][e]/u_r, computed once by the winner's workgroup
 };
 
 // ---- granules -------------------------------------------------------------------------------
@@ -111,7 +112,7 @@ struct Shared {
 };
 
 __host__ __device__ inline size_t resident_lds_bytes(int mpad) {
-    return sizeof(double) * ((size_t)RS_CPT + 8 + 2 * (size_t)mpad) + sizeof(lpdev::BlockSelScratch) + 64 +
+    return sizeof(double) * ((size_t)RS_CPT + 8 + 2 * (size_t)mpad) + sizeof(lpdev::BlockSelScratch) + 80 +
            sizeof(int) * (size_t)mpad;
 }
 
@@ -136,7 +137,7 @@ __device__ __forceinline__ void stage_candidate(double up, double xb, bool rowok
     lpdev::block_select_stage1<false>(ratio, sh.sc);
 }
 
-template <int CPT>
+template <int CPT, bool STAMPS>
 __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, ResidentDev rd) {
     static_assert(CPT == 32, "the slab holds 32 columns");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
     sh.u = sh.ratio + mpad;
     sh.sc = reinterpret_cast<lpdev::BlockSelScratch*>(sh.u + mpad);
     sh.ctl = reinterpret_cast<Ctl*>(sh.sc + 1);
-    sh.basis = reinterpret_cast<int*>(reinterpret_cast<char*>(sh.ctl) + 64);
+    sh.basis = reinterpret_cast<int*>(reinterpret_cast<char*>(sh.ctl) + 80);
 
     Comm cm;
     cm.r = __builtin_amdgcn_make_buffer_rsrc(rd.comm, 0, rd.comm_bytes, 0x00020000);
@@ -229,62 +230,127 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
     const bool plain = sh.ctl->plain != 0;
     if (sh.ctl->fail) status = kResidentFailed;
 
-    unsigned long long* stamps = (rd.stamps && k == 0 && tid == 0) ? rd.stamps : nullptr;
-#define RS_STAMP(s)                                                                        \
-    do {                                                                                   \
-        if (stamps && it < 4096) stamps[(size_t)it * 8 + (s)] = __builtin_readcyclecounter(); \
+    // Diagnostic build only (STAMPS): cycles of every phase of workgroup 0's wave 0, summed over the
+    // solve in registers and stored once at the end (a store per stamp would sit in front of every
+    // later vmcnt wait and distort what it measures).
+    unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = STAMPS ? __builtin_readcyclecounter() : 0;
+#define RS_STAMP(s)                                                          \
+    do {                                                                     \
+        if (STAMPS) {                                                        \
+            const unsigned long long now_ = __builtin_readcyclecounter();    \
+            acc[(s)] += now_ - tprev;                                        \
+            tprev = now_;                                                    \
+        }                                                                    \
     } while (0)
 
-    unsigned ep = 0;
-    while (status == kRunning) {
-        ++ep;
-        const unsigned par = ep & 1u;
-        const unsigned slot = par * (unsigned)G + (unsigned)k;
-        RS_STAMP(0);
-        // ================= publish: this workgroup's candidate ==================================
-        // Pricing summary of my columns (:152-174; minimisation scans -d with the same rule).
-        // Every wave computes it from its own replica (lane l = column l): no barrier, no LDS.
-        const double pv = nbl ? nan_to(maximize ? dl : -dl, -INFINITY) : -INFINITY;
-        const unsigned long long pkey = lpdev::f64_sort_key(pv);
-        const unsigned long long mkey = lpdev::wave_ext_key<true>(pkey);
-        const unsigned long long hit = __ballot(nbl && pkey == mkey && pkey != kNegInf);
-        const int jl = hit ? (int)__builtin_ctzll(hit) : -1;
-        double up = 0.0;
+    // One pivot, in the order the dependencies allow:
+    //   decide(p)  -> pivot row of p through LDS -> reduced-cost row of p+1 (needs only that row)
+    //   -> pricing(p+1) -> the ONE candidate column of p+1 updated ahead of the rest -> publish it,
+    //   its record A, first half of its ratio test -> record B
+    //   -> rank-1 update of all 32 columns, which runs while the records travel -> decide(p+1).
+    unsigned ep = 0, par = 0, slot = 0;
+    double pv = 0.0, up = 0.0;
+    unsigned long long pkey = 0, mkey = 0, hit = 0;
+    int jl = -1;
+    // wave 0 issues its first poll of the records right after publishing, so that the round trip
+    // runs under the rank-1 update; the values are looked at only when the update is done
+    const int R = (G + 63) >> 6;      // records per lane (blocked: lane order = column order)
+    const int q0 = lane * R;
+    v4i pfa = {0, 0, 0, 0}, pfb = {0, 0, 0, 0};
+    v4i pfB0 = {0, 0, 0, 0}, pfB1 = {0, 0, 0, 0}, pfB2 = {0, 0, 0, 0}, pfB3 = {0, 0, 0, 0},
+        pfB4 = {0, 0, 0, 0};   // record B of record q0 (R == 1 only)
+    bool pf = false;
+#define RS_PREFETCH()                                                                     \
+    do {                                                                                  \
+        if (wave == 0 && q0 < G) {                                                        \
+            const unsigned base = cm.recA + (par * (unsigned)G + (unsigned)q0) * 32u;     \
+            pfa = ld16(cm.r, base);                                                       \
+            pfb = ld16(cm.r, base + 16);                                                  \
+            pf = true;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+    // pricing summary of my columns (:152-174; minimisation scans -d with the same rule).  Every
+    // wave computes it from its own replica (lane l = column l): no barrier, no LDS.
+#define RS_PRICE()                                                                 \
+    do {                                                                           \
+        pv = nbl ? nan_to(maximize ? dl : -dl, -INFINITY) : -INFINITY;             \
+        pkey = lpdev::f64_sort_key(pv);                                            \
+        mkey = lpdev::wave_ext_key<true>(pkey);                                    \
+        hit = __ballot(nbl && pkey == mkey && pkey != kNegInf);                    \
+        jl = hit ? (int)__builtin_ctzll(hit) : -1;                                 \
+    } while (0)
+
+    // publication of my candidate (column values UP for the rows, xB values XBV): record A {M_k,
+    // column} first — the consumers' decision needs nothing else from most workgroups — then the
+    // column, the first half of the ratio test, and record B {P_k, u_r, leaving row} from wave W2.
+#define RS_PUBLISH(UP, XBV)                                                                          \
+    do {                                                                                             \
+        ++ep;                                                                                        \
+        par = ep & 1u;                                                                               \
+        slot = par * (unsigned)G + (unsigned)k;                                                      \
+        if (wave == 0) {                                                                             \
+            if (lane < 2) {                                                                          \
+                const v4i g = lane == 0 ? g_pack(ep, hit ? lpdev::f64_from_key(mkey) : -INFINITY)    \
+                                        : g_pack2(ep, jl >= 0 ? col0 + jl : -1, 0);                  \
+                st16(g, cm.r, cm.recA + slot * 32u + (unsigned)lane * 16u, plain);                   \
+            }                                                                                        \
+            if (lane < CPT) /* all my reduced costs, for the slow path */                            \
+                st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);    \
+        }                                                                                            \
+        if (jl >= 0) stage_candidate((UP), (XBV), rowok, eps, ep, cm, cm.col + slot * col_stride, plain, sh); \
+        RS_STAMP(8);                                                                                 \
+        __syncthreads();                                                                             \
+        RS_STAMP(9);                                                                                \
+        if (wave == W2) {                                                                            \
+            const unsigned long long pk = lpdev::wave_ext_key<true>((lane < jl) ? pkey : kNegInf);   \
+            int rk = -2;                                                                             \
+            double urk = 0.0;                                                                        \
+            if (jl >= 0) {                                                                           \
+                rk = lpdev::block_select_stage2<false>(sh.ratio, m, eps, sh.sc);                     \
+                urk = (rk >= 0) ? sh.u[rk] : 0.0;                                                    \
+            }                                                                                        \
+            /* the two wave-uniform quotients of the update (F(r,r) = 1/u_r, :204, and the reduced-cost   \
+               row's -d_e/u_r) are computed HERE, once, off the consumers' critical path */              \
+            const double Mk_ = hit ? lpdev::f64_from_key(mkey) : 0.0;                                \
+            const double invk = (rk >= 0) ? 1.0 / urk : 0.0;                                         \
+            const double lmk = (rk >= 0) ? -(maximize ? Mk_ : -Mk_) / urk : 0.0;                     \
+            if (lane < 5) {                                                                          \
+                const v4i g = lane == 0 ? g_pack(ep, lpdev::f64_from_key(pk))                        \
+                            : lane == 1 ? g_pack(ep, urk)                                            \
+                            : lane == 2 ? g_pack2(ep, rk, 0)                                         \
+                            : lane == 3 ? g_pack(ep, invk) : g_pack(ep, lmk);                        \
+                st16(g, cm.r, cm.recB + slot * 96u + (unsigned)lane * 16u, plain);                   \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+
+    // records B are published later than records A (after the ratio test): their first poll is issued
+    // at the end of the rank-1 update
+#define RS_PREFETCH_B()                                                                   \
+    do {                                                                                  \
+        if (wave == 0 && R == 1 && q0 < G) {                                              \
+            const unsigned base = cm.recB + (par * (unsigned)G + (unsigned)q0) * 96u;     \
+            pfB0 = ld16(cm.r, base);                                                      \
+            pfB1 = ld16(cm.r, base + 16u);                                                \
+            pfB2 = ld16(cm.r, base + 32u);                                                \
+            pfB3 = ld16(cm.r, base + 48u);                                                \
+            pfB4 = ld16(cm.r, base + 64u);                                                \
+        }                                                                                 \
+    } while (0)
+
+    if (status == kRunning) {   // prologue: candidate of the initial tableau
+        RS_PRICE();
         if (jl >= 0) up = RS_SLAB_GET(jl);
-        if (wave == 0) {
-            // record A: {M_k, entering column}; the consumers' decision needs nothing else from most
-            // workgroups, and it propagates while the ratio test below runs
-            if (lane < 2) {
-                const v4i g = lane == 0 ? g_pack(ep, hit ? lpdev::f64_from_key(mkey) : -INFINITY)
-                                        : g_pack2(ep, jl >= 0 ? col0 + jl : -1, 0);
-                st16(g, cm.r, cm.recA + slot * 32u + (unsigned)lane * 16u, plain);
-            }
-            if (lane < CPT)   // all my reduced costs, for the slow path
-                st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);
-        }
-        if (jl >= 0) stage_candidate(up, xb, rowok, eps, ep, cm, cm.col + slot * col_stride, plain, sh);
-        RS_STAMP(1);
-        __syncthreads();
-        if (wave == W2) {
-            // record B: {P_k, u_r, leaving row} of my candidate — read only if my candidate wins
-            const unsigned long long pk = lpdev::wave_ext_key<true>((lane < jl) ? pkey : kNegInf);
-            int rk = -2;
-            double urk = 0.0;
-            if (jl >= 0) {
-                rk = lpdev::block_select_stage2<false>(sh.ratio, m, eps, sh.sc);
-                urk = (rk >= 0) ? sh.u[rk] : 0.0;
-            }
-            if (lane < 3) {
-                const v4i g = lane == 0 ? g_pack(ep, lpdev::f64_from_key(pk))
-                                        : (lane == 1 ? g_pack(ep, urk) : g_pack2(ep, rk, 0));
-                st16(g, cm.r, cm.recB + slot * 64u + (unsigned)lane * 16u, plain);
-            }
-        }
-        RS_STAMP(2);
+        RS_PUBLISH(up, xb);
+        RS_PREFETCH();
+        RS_PREFETCH_B();
+    }
+    while (status == kRunning) {
+        RS_STAMP(0);
         // ================= consume: everyone's records, one decision ============================
         if (wave == 0) {
-            const int R = (G + 63) >> 6;                 // records per lane (blocked: lane order = column order)
-            const int q0 = lane * R;
             double Ml = -INFINITY;
             int el = -1, ql = -1;
             Spin spin;
@@ -296,7 +362,14 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     const int q = q0 + t;
                     if (q >= G) break;
                     const unsigned base = cm.recA + (par * (unsigned)G + (unsigned)q) * 32u;
-                    const v4i a = ld16(cm.r, base), b = ld16(cm.r, base + 16);
+                    v4i a, b;
+                    if (t == 0 && pf) {
+                        a = pfa;
+                        b = pfb;
+                    } else {
+                        a = ld16(cm.r, base);
+                        b = ld16(cm.r, base + 16);
+                    }
                     ok &= g_fresh(a, ep) && g_fresh(b, ep);
                     const double Mq = g_f64(a);
                     if (b.y >= 0 && Mq > Ml) {           // strictly greater: ties keep the earlier column
@@ -305,6 +378,7 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                         ql = q;
                     }
                 }
+                pf = false;
                 if (__all(ok)) break;
                 if (spin.expired(cm.r, cm.abort)) {
                     failed = true;
@@ -313,12 +387,13 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     break;
                 }
             }
+            RS_STAMP(1);
             const unsigned long long Mlk = lpdev::f64_sort_key(Ml);
             const unsigned long long Mk = lpdev::wave_ext_key<true>(Mlk);
             const double M = lpdev::f64_from_key(Mk);
             const unsigned long long whit = __ballot(ql >= 0 && Mlk == Mk);
             int mode, kst = 0, e = -1, r = -1;
-            double ur = 0.0;
+            double ur = 0.0, inv = 0.0, lm = 0.0;
             if (failed) {
                 mode = MODE_FAIL;
                 if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
@@ -328,11 +403,30 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 const int W = (int)__builtin_ctzll(whit);
                 kst = __builtin_amdgcn_readlane(ql, W);
                 e = __builtin_amdgcn_readlane(el, W);
+                // record B of the winner {P_k*, u_r, leaving row}: its loads travel while P is assembled
+                const unsigned baseB = cm.recB + (par * (unsigned)G + (unsigned)kst) * 96u;
+                v4i b0, b1, b2, b3, b4;
+                const bool pfB_ok = R == 1 && g_fresh(pfB0, ep) && g_fresh(pfB1, ep) && g_fresh(pfB2, ep) &&
+                                    g_fresh(pfB3, ep) && g_fresh(pfB4, ep);
+                if (__builtin_amdgcn_readlane((int)pfB_ok, W)) {   // the prefetched copy (lane k* holds record k*)
+                    b0.x = b0.z = b1.x = b1.z = b2.x = b2.z = b3.x = b3.z = b4.x = b4.z = (int)ep;
+                    b0.y = __builtin_amdgcn_readlane(pfB0.y, W); b0.w = __builtin_amdgcn_readlane(pfB0.w, W);
+                    b1.y = __builtin_amdgcn_readlane(pfB1.y, W); b1.w = __builtin_amdgcn_readlane(pfB1.w, W);
+                    b2.y = __builtin_amdgcn_readlane(pfB2.y, W); b2.w = 0;
+                    b3.y = __builtin_amdgcn_readlane(pfB3.y, W); b3.w = __builtin_amdgcn_readlane(pfB3.w, W);
+                    b4.y = __builtin_amdgcn_readlane(pfB4.y, W); b4.w = __builtin_amdgcn_readlane(pfB4.w, W);
+                } else {
+                    b0 = ld16(cm.r, baseB);
+                    b1 = ld16(cm.r, baseB + 16u);
+                    b2 = ld16(cm.r, baseB + 32u);
+                    b3 = ld16(cm.r, baseB + 48u);
+                    b4 = ld16(cm.r, baseB + 64u);
+                }
                 // P = extreme of everything in front of the winner's first maximum: the lanes before the
                 // winner's lane, the records of the winner's own lane in front of the winner (only when a
                 // lane holds several records, G > 64), and P_k* from the winner's record B
                 const unsigned long long Ppk = lpdev::wave_ext_key<true>((lane < W) ? Mlk : kNegInf);
-                double Pin_lane = -INFINITY;             // records of the winner's lane in front of the winner
+                double Pin_lane = -INFINITY;
                 if (R > 1 && lane == W) {
                     for (int t = 0; t < R; ++t) {
                         const int q = q0 + t;
@@ -343,23 +437,23 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     }
                 }
                 Pin_lane = lpdev::wave_bcast_f64(Pin_lane, W);
-                // record B of the winner
-                const unsigned baseB = cm.recB + (par * (unsigned)G + (unsigned)kst) * 64u;
-                v4i b0, b1, b2;
                 Spin spinB;
-                for (;;) {
-                    b0 = ld16(cm.r, baseB);
-                    b1 = ld16(cm.r, baseB + 16u);
-                    b2 = ld16(cm.r, baseB + 32u);
-                    if (g_fresh(b0, ep) && g_fresh(b1, ep) && g_fresh(b2, ep)) break;
+                while (!(g_fresh(b0, ep) && g_fresh(b1, ep) && g_fresh(b2, ep) && g_fresh(b3, ep) && g_fresh(b4, ep))) {
                     if (spinB.expired(cm.r, cm.abort)) {
                         failed = true;
                         break;
                     }
+                    b0 = ld16(cm.r, baseB);
+                    b1 = ld16(cm.r, baseB + 16u);
+                    b2 = ld16(cm.r, baseB + 32u);
+                    b3 = ld16(cm.r, baseB + 48u);
+                    b4 = ld16(cm.r, baseB + 64u);
                 }
                 const double P = fmax(fmax(lpdev::f64_from_key(Ppk), Pin_lane), g_f64(b0));
                 ur = g_f64(b1);
                 r = b2.y;
+                inv = g_f64(b3);
+                lm = g_f64(b4);
                 if (failed) {
                     mode = MODE_FAIL;
                     if (lane == 0) sh.ctl->fail = 6;   // code 6: record B of the winner
@@ -372,13 +466,15 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             if (lane == 0) {
                 Ctl* c = sh.ctl;
                 c->mode = mode; c->kst = kst; c->e = e; c->r = r;
-                c->ur = ur; c->dE = M;
+                c->ur = ur; c->dE = M; c->inv = inv; c->lm = lm;
                 c->oldb = (mode == MODE_PIVOT) ? sh.basis[r] : -1;
             }
+            RS_STAMP(2);
         }
         __syncthreads();
         RS_STAMP(3);
         int mode = sh.ctl->mode;
+        if (sh.ctl->fail) mode = MODE_FAIL;
         bool from_colS = false;
         if (mode == MODE_SLOW) {
             // ---- exact replay of the scan over all n published reduced costs (near-tie)
@@ -425,8 +521,13 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     if (wave == 0) {
                         const int r2 = lpdev::block_select_stage2<false>(sh.ratio, m, eps, sh.sc);
                         const double ur2 = (r2 >= 0) ? sh.u[r2] : 0.0;
-                        if (lane < 2) {
-                            const v4i g = lane == 0 ? g_pack(ep, ur2) : g_pack2(ep, r2, 0);
+                        const double dE2 = maximize ? sh.ctl->dE : -sh.ctl->dE;
+                        const double inv2 = (r2 >= 0) ? 1.0 / ur2 : 0.0;
+                        const double lm2 = (r2 >= 0) ? -dE2 / ur2 : 0.0;
+                        if (lane < 4) {
+                            const v4i g = lane == 0 ? g_pack(ep, ur2)
+                                        : lane == 1 ? g_pack2(ep, r2, 0)
+                                        : lane == 2 ? g_pack(ep, inv2) : g_pack(ep, lm2);
                             st16(g, cm.r, cm.recS + par * 64u + (unsigned)lane * 16u, plain);
                         }
                     }
@@ -435,11 +536,13 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 if (wave == 0) {
                     Spin spin;
                     bool failed = false;
-                    v4i a, b;
+                    v4i a, b, c2, d2;
                     for (;;) {
                         a = ld16(cm.r, cm.recS + par * 64u);
                         b = ld16(cm.r, cm.recS + par * 64u + 16u);
-                        if (g_fresh(a, ep) && g_fresh(b, ep)) break;
+                        c2 = ld16(cm.r, cm.recS + par * 64u + 32u);
+                        d2 = ld16(cm.r, cm.recS + par * 64u + 48u);
+                        if (g_fresh(a, ep) && g_fresh(b, ep) && g_fresh(c2, ep) && g_fresh(d2, ep)) break;
                         if (spin.expired(cm.r, cm.abort)) {
                             failed = true;
                             break;
@@ -449,6 +552,8 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                         Ctl* c = sh.ctl;
                         c->ur = g_f64(a);
                         c->r = b.y;
+                        c->inv = g_f64(c2);
+                        c->lm = g_f64(d2);
                         c->mode = failed ? MODE_FAIL : (b.y < 0 ? MODE_UNBOUNDED : MODE_PIVOT);
                         if (failed) c->fail = 4;   // code 4: slow-path second hop
                         c->oldb = (!failed && b.y >= 0) ? sh.basis[b.y] : -1;
@@ -468,30 +573,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         const int r = __builtin_amdgcn_readfirstlane(sh.ctl->r);
         const int oldb = __builtin_amdgcn_readfirstlane(sh.ctl->oldb);
         const double ur = sh.ctl->ur;
-        const double dE = maximize ? sh.ctl->dE : -sh.ctl->dE;   // T[m][e], the entering column's reduced cost
-        // ---- entering column: the winner's published candidate (mine is still in a register).
-        // The load is issued first; the two wave-uniform quotients of the update run under it.
-        double u = up;
-        const bool need_col = kst != k && rowok;
-        const unsigned coff = (from_colS ? cm.colS + par * col_stride
-                                         : cm.col + (par * (unsigned)G + (unsigned)kst) * col_stride) +
-                              (unsigned)tid * 16u;
-        v4i gcol = {0, 0, 0, 0};
-        if (need_col) gcol = ld16(cm.r, coff);
-        const double inv = 1.0 / ur;      // F(r,r), :204
-        const double lm = -dE / ur;       // F row of the reduced costs
-        if (need_col) {
-            Spin spin;
-            while (!g_fresh(gcol, ep)) {
-                if (spin.expired(cm.r, cm.abort)) {
-                    sh.ctl->fail = 5;   // code 5: entering column
-                    break;
-                }
-                gcol = ld16(cm.r, coff);
-            }
-            u = g_f64(gcol);
-        }
-        RS_STAMP(4);
         // ---- my part of the pivot row (before scaling), broadcast through LDS
         if (tid == r) {
 #pragma unroll
@@ -501,37 +582,21 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             }
             sh.prow[CPT] = xb;
         }
-        const double l = -u / ur;         // F(i,r), :201 (rows other than r)
+        // ---- entering column: the winner's published candidate (mine is still in a register; after the
+        // slow path it is the owner's second-hop column).  Requested now, awaited after the next pricing.
+        const bool want_col = kst != k && rowok;
+        const unsigned coff = (from_colS ? cm.colS + par * col_stride
+                                         : cm.col + (par * (unsigned)G + (unsigned)kst) * col_stride) +
+                              (unsigned)tid * 16u;
+        v4i gcol = {0, 0, 0, 0};
+        if (want_col) gcol = ld16(cm.r, coff);
+        const unsigned ep_col = ep;
+        const double inv = sh.ctl->inv;   // F(r,r) = 1/u_r, :204
+        const double lm = sh.ctl->lm;     // F row of the reduced costs: -T[m][e]/u_r
+        RS_STAMP(4);
         __syncthreads();
-        if (sh.ctl->fail) {
-            status = kResidentFailed;
-            break;
-        }
         RS_STAMP(5);
-        // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204)
-        if (rowok) {
-            if (tid == r) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    Ta[j] = Ta[j] * inv;
-                    Tb[j] = Tb[j] * inv;
-                }
-                xb = xb * inv;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    Ta[j] = fma(l, sh.prow[j], Ta[j]);
-                    Tb[j] = fma(l, sh.prow[16 + j], Tb[j]);
-                }
-                xb = fma(l, sh.prow[CPT], xb);
-            }
-            if (kst == k) {   // column e becomes the unit vector
-                const int je = e - col0;
-                const double unit = (tid == r) ? 1.0 : 0.0;
-                RS_SLAB_SET(je, unit);
-            }
-        }
-        // reduced-cost row (row m of the tableau), replicated per wave
+        // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave
         if (colok) {
             dl = (mycol == e) ? 0.0 : fma(lm, sh.prow[lane], dl);
             if (mycol == e) nbl = false;
@@ -545,11 +610,81 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 d.trace_leave[it] = r;
             }
         }
-        RS_STAMP(6);
         ++it;
-        if (it >= max_iter) status = LP_ITER_LIMIT;   // :450
+        const bool last = it >= max_iter;   // :450: this pivot is applied, no further one is chosen
+        if (!last) RS_PRICE();
+        RS_STAMP(6);
+        // ---- the entering column has arrived by now
+        double u = up;
+        if (want_col) {
+            Spin spin;
+            while (!g_fresh(gcol, ep_col)) {
+                if (spin.expired(cm.r, cm.abort)) {
+                    sh.ctl->fail = 5;   // code 5: entering column (acted on at the next decision barrier)
+                    break;
+                }
+                gcol = ld16(cm.r, coff);
+            }
+            u = g_f64(gcol);
+        }
+        const double l = -u / ur;         // F(i,r), :201 (rows other than r)
+        const double xbn = (tid == r) ? xb * inv : fma(l, sh.prow[CPT], xb);
+        RS_STAMP(7);
+        if (!last) {
+            // the candidate column of the NEXT pivot, updated ahead of the other 31 (same operation,
+            // same operands as the full update below: identical bits)
+            double upn = 0.0;
+            if (jl >= 0) {
+                const double t = RS_SLAB_GET(jl);
+                upn = (tid == r) ? t * inv : fma(l, sh.prow[jl], t);
+            }
+            RS_PUBLISH(upn, xbn);
+            up = upn;
+            RS_PREFETCH();
+        }
+        RS_STAMP(10);
+        // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204);
+        // the records published above are travelling meanwhile
+        if (rowok) {
+            if (tid == r) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    Ta[j] = Ta[j] * inv;
+                    Tb[j] = Tb[j] * inv;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
+            }
+        }
+        if (!last) RS_PREFETCH_B();   // the records B are out by now; their round trip runs under the second half
+        if (rowok) {
+            if (tid != r) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Tb[j] = fma(l, sh.prow[16 + j], Tb[j]);
+            }
+            if (kst == k) {   // column e becomes the unit vector
+                const double unit = (tid == r) ? 1.0 : 0.0;
+                switch (e - col0) {
+#define RS_CASE(J)                  \
+    case J: Ta[J] = unit; break;    \
+    case 16 + J: Tb[J] = unit; break;
+                    RS_CASE(0) RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
+                    RS_CASE(8) RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15)
+#undef RS_CASE
+                    default: break;
+                }
+            }
+        }
+        xb = xbn;
+        RS_STAMP(11);
+        if (last) status = LP_ITER_LIMIT;
     }
 #undef RS_STAMP
+#undef RS_PRICE
+#undef RS_PUBLISH
+#undef RS_PREFETCH
+#undef RS_PREFETCH_B
 
     if (status == kResidentFailed) {   // nothing is written back: the host reruns on another path
         if (tid == 0) {
@@ -562,6 +697,8 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         }
         return;
     }
+    if (STAMPS && rd.stamps && tid == 0)
+        for (int q = 0; q < 16; ++q) rd.stamps[(size_t)k * 16 + q] = acc[q];
     // ---- write the tableau back (row-major (m+1) x ld, what every other entry point reads)
     if (rowok) {
         double* Trow = d.T + (size_t)tid * ld;
@@ -618,7 +755,7 @@ int lp_resident_plan(int m, int n, ResidentDev* out) {
     r.abort_off = take(256);
     r.census_off = take((size_t)G * 16);
     r.recA_off = take((size_t)2 * G * 32);
-    r.recB_off = take((size_t)2 * G * 64);
+    r.recB_off = take((size_t)2 * G * 96);
     r.recS_off = take(2 * 64);
     r.dpub_off = take((size_t)2 * G * RS_CPT * 16);
     r.colS_off = take((size_t)2 * r.mpad * 16);
@@ -637,15 +774,20 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     // > 80 KiB of LDS per workgroup: one workgroup per CU, so that G workgroups own G CUs
     size_t shm = resident_lds_bytes(rd.mpad);
     if (shm < 84 * 1024) shm = 84 * 1024;
-    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_resident<RS_CPT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    const bool stamped = rd.stamps != nullptr;
+    const void* kfn = stamped ? reinterpret_cast<const void*>(k_simplex_resident<RS_CPT, true>)
+                              : reinterpret_cast<const void*>(k_simplex_resident<RS_CPT, false>);
+    LP_HIP(ctx, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     ResidentDev rdv = rd;
     if (getenv("LP_RESIDENT_FORCE_SC1")) rdv.pad0 |= 1;      // diagnostics: write-through stores on one XCD too
     if (getenv("LP_RESIDENT_SPREAD")) rdv.stride = 1;        // diagnostics: participants on all XCDs
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_resident_state_init, 1, 1, 0, s, d, eps, max_iter);
     LP_HIP(ctx, hipMemsetAsync(rd.comm, 0, rd.comm_bytes, s));   // every tag of every granule: epoch 0
-    hipLaunchKernelGGL(k_simplex_resident<RS_CPT>, rdv.G * rdv.stride, rdv.mpad, shm, s, d, rdv);
+    if (stamped)
+        hipLaunchKernelGGL((k_simplex_resident<RS_CPT, true>), rdv.G * rdv.stride, rdv.mpad, shm, s, d, rdv);
+    else
+        hipLaunchKernelGGL((k_simplex_resident<RS_CPT, false>), rdv.G * rdv.stride, rdv.mpad, shm, s, d, rdv);
     LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipEventSynchronize(p->ev1));
