@@ -52,12 +52,33 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/): bench.py cannot
-    run rocprofv3 on itself; the collection recipe is in profiles/README.md."""
+def kernel_source_hash():
+    """sha256 over the HIP sources: a committed PMC file counts only for the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "simplexmethod_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile():
+    """profiles/r02_pmc_traffic.json (written by scripts/pmc_to_json.py from two separate rocprofv3
+    --pmc passes, FETCH_SIZE and WRITE_SIZE, of scripts/pmc_traffic.py): HBM bytes per launch of the
+    tableau kernels.  bench.py cannot run rocprofv3 on itself, so the figures are reported only when
+    the file was taken on exactly these kernel sources; otherwise traffic is null."""
     try:
-        data = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_update_traffic.json")))
-        return float(data[kernel]["hbm_bytes_per_launch"])
+        data = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    except Exception:
+        return {}
+    return data if data.get("kernel_source_hash") == kernel_source_hash() else {}
+
+
+def traffic_of(prof, kernel):
+    try:
+        return float(prof["kernels"][kernel]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -65,34 +86,36 @@ def pmc_traffic(kernel):
 def pivot_leg(ctx, args):
     """Simplex on the m=512 x n=1024 random LP (BASELINE configs[1]).
 
-    roofline = the dominant kernel of the solve, the rank-J tableau update of the look-ahead
-    path: ALGORITHMIC bytes per launch = (pivots it applies) x 16*m*(n+1)  [SURVEY.md 8(d):
-    one pivot reads and writes every tableau element once], divided by the launch duration
-    measured with HIP events on the solver's stream.  Also reported: the whole-solve rate
-    (selector + update + launch gaps) and the classic one-launch-per-pivot rank-1 update."""
+    Every figure is ALGORITHMIC bytes (one pivot reads and writes every tableau
+    element once, 16*m*(n+1) B) divided by a HIP-event time on the solver's stream, so a fraction
+    of the 8 TB/s HBM peak can exceed 1 only if the kernel does not move those bytes - which is
+    stated next to it (traffic, bytes moved by construction)."""
     from simplexmethod_amd import capi
     m, n = args.pivot_m, args.pivot_n
     A, b, c, basis = capi.gen_lp(0, m, n)
     p = ctx.simplex_problem(A, b, c, basis, True, n - m)
     bytes_per_pivot = 16.0 * m * (n + 1)
-    rc, st = p.run(algo=args.simplex_algo)          # warm-up solve
-    best = None
-    for _ in range(5):
-        p.reset()
-        rc, st = p.run(algo=args.simplex_algo)
-        cur = dict(solve_ms=st.solve_ms, pivots=st.pivots, launches=st.launches)
-        if best is None or cur["solve_ms"] < best["solve_ms"]:
-            best = cur
-    # one more solve with every tableau-update launch bracketed by HIP events (slower: the
-    # events add ~1-2 us per launch, which is why solve_ms comes from the runs above)
-    p.profile(True)
-    best["update_ms"], best["update_launches"] = 0.0, 0
-    for _ in range(3):
-        p.reset()
-        rc, st = p.run(algo=args.simplex_algo)
-        if st.update_launches and (best["update_launches"] == 0 or st.update_ms < best["update_ms"]):
-            best["update_ms"], best["update_launches"] = st.update_ms, st.update_launches
-    p.profile(False)
+    prof = pmc_profile() if (m, n) == (512, 1024) else {}
+
+    def best_of(algo, reps=7):
+        best = None
+        for _ in range(reps):
+            p.reset()
+            rc, st = p.run(algo=algo)
+            cur = dict(rc=int(rc), solve_ms=st.solve_ms, pivots=st.pivots, launches=st.launches,
+                       kernel_ms=st.update_ms, kernel_launches=st.update_launches)
+            if best is None or cur["solve_ms"] < best["solve_ms"]:
+                best = cur
+        return best
+
+    p.run(algo=args.simplex_algo)                   # warm-up solve
+    auto = best_of(args.simplex_algo)
+    pivots = max(auto["pivots"], 1)
+    resident = auto["launches"] == 2 and auto["kernel_launches"] == 1   # the chip-resident path ran
+    try:
+        look = best_of(capi.SIMPLEX_LOOKAHEAD, 3)
+    except capi.LPError:
+        look = None
     p.reset()
     upd1_ms = min(p.bench_update(0, 0, 200) for _ in range(3))   # ms per rank-1 update launch
     try:   # rank-J update alone: 200 back-to-back launches between two events
@@ -101,49 +124,75 @@ def pivot_leg(ctx, args):
     except capi.LPError:
         updj = None
     p.free()
-    pivots = max(best["pivots"], 1)
+    # one-shot entry point: host buffers in, host buffers out (upload, solve, download, free)
+    ctx.simplex_solve(A, b, c, basis, True, n - m)
+    t_one = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.simplex_solve(A, b, c, basis, True, n - m)
+        t_one = min(t_one, time.perf_counter() - t0)
+
     out = {
         "workload": f"simplex m={m} n={n} seed=0 (BASELINE configs[1])",
-        "status": int(rc), "pivots": int(best["pivots"]), "launches": int(best["launches"]),
-        "solve_ms": round(best["solve_ms"], 3),
-        "us_per_pivot_whole_solve": round(1e3 * best["solve_ms"] / pivots, 3),
-        "whole_solve_equiv_GBs": round(bytes_per_pivot * pivots / (best["solve_ms"] * 1e-3) / 1e9, 1),
-        "rank1_update_us_per_launch": round(1e3 * upd1_ms, 3),
-        "rank1_update_GBs": round(bytes_per_pivot / (upd1_ms * 1e-3) / 1e9, 1),
-        "rank1_update_traffic_bytes": pmc_traffic("k_simplex_update") if (m, n) == (512, 1024) else None,
+        "algorithm": "chip-resident tableau (one launch per solve)" if resident else "launch-based",
+        "status": auto["rc"], "pivots": int(auto["pivots"]), "launches": int(auto["launches"]),
+        "solve_ms": round(auto["solve_ms"], 3),
+        "us_per_pivot_whole_solve": round(1e3 * auto["solve_ms"] / pivots, 3),
+        "one_shot_host_buffers_ms": round(1e3 * t_one, 3),
+        "budget_us_per_pivot_at_70pct_of_8TBs": round(bytes_per_pivot / (0.7 * HBM_PEAK_GBS * 1e9) * 1e6, 3),
     }
-    if best["update_launches"] > 0 and best["update_ms"] > 0:
-        out["update_launch_us_inside_solve_event_bracketed"] = round(
-            1e3 * best["update_ms"] / best["update_launches"], 3)
+    if look is not None:
+        out["lookahead_path_solve_ms"] = round(look["solve_ms"], 3)
+        out["lookahead_path_us_per_pivot"] = round(1e3 * look["solve_ms"] / max(look["pivots"], 1), 3)
+
+    whole = bytes_per_pivot * pivots / (auto["solve_ms"] * 1e-3) / 1e9
+    roofline_whole = {
+        "what": "whole pivot (pricing + ratio test + update + hand-offs): algorithmic bytes / (solve time / pivots)",
+        "bound": "hbm", "achieved": round(whole, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(whole / HBM_PEAK_GBS, 4), "us_per_pivot": out["us_per_pivot_whole_solve"],
+    }
+    r1 = bytes_per_pivot / (upd1_ms * 1e-3) / 1e9
+    roofline_rank1 = {
+        "kernel": "k_simplex_update (rank-1 Gauss-Jordan update, one launch per pivot: the tableau streams "
+                  "through HBM/L2 once per pivot; the path for tableaus that do not fit on chip)",
+        "bound": "hbm", "achieved": round(r1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(r1 / HBM_PEAK_GBS, 4), "traffic": traffic_of(prof, "k_simplex_update"),
+        "launches": 200, "avg_launch_us": round(1e3 * upd1_ms, 3),
+        "algorithmic_bytes_per_launch": bytes_per_pivot,
+    }
+    rankj = None
     if updj is not None:
-        per_launch_ms, pivots_per_launch = updj
-        achieved = bytes_per_pivot * pivots_per_launch / (per_launch_ms * 1e-3) / 1e9
-        roofline = {
-            "kernel": "k_look_update (rank-J Gauss-Jordan update: J staged pivots applied in one "
-                      "pass over the tableau)",
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("k_look_update") if (m, n) == (512, 1024) else None,
-            "launches": 200,
+        per_launch_ms, J = updj
+        moved = 2.0 * 8.0 * (m + 1) * (8 * ((n + 1 + 7) // 8))     # one read + one write of the padded tableau
+        rankj = {
+            "kernel": "k_look_update (rank-J update of the look-ahead path)", "J": int(J),
             "avg_launch_us": round(1e3 * per_launch_ms, 3),
-            "pivots_per_launch": int(pivots_per_launch),
-            "algorithmic_bytes_per_launch": round(bytes_per_pivot * pivots_per_launch, 1),
-            "hbm_bytes_per_launch_by_construction": 2.0 * 8.0 * (m + 1) * (8 * ((n + 1 + 7) // 8)),
-            "note": "achieved = algorithmic bytes (16*m*(n+1) per pivot, SURVEY 8(d)) x J pivots "
-                    "per launch / (HIP-event time of 200 back-to-back launches / 200, launch "
-                    "boundary included); each launch moves the tableau once (read + write), "
-                    "i.e. 1/J of the algorithmic bytes - see hbm_bytes_per_launch_by_construction",
+            "bytes_moved_per_launch_by_construction": moved,
+            "bytes_moved_GBs": round(moved / (per_launch_ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak_by_bytes_moved": round(moved / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic_of(prof, "k_look_update"),
+            "algorithmic_equiv_GBs_no_frac": round(bytes_per_pivot * J / (per_launch_ms * 1e-3) / 1e9, 1),
+        }
+    if resident and auto["kernel_ms"] > 0:
+        k = bytes_per_pivot * pivots / (auto["kernel_ms"] * 1e-3) / 1e9
+        roofline = {
+            "kernel": "k_simplex_resident (every pivot of the solve in ONE launch: the tableau stays in the "
+                      "registers of ceil(n/32) co-resident workgroups; per pivot one all-to-all hand-off of "
+                      "a 32-byte record and a 4 KB column per workgroup through L2)",
+            "bound": "hbm", "achieved": round(k, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(k / HBM_PEAK_GBS, 4), "traffic": traffic_of(prof, "k_simplex_resident"),
+            "launches": 1, "avg_launch_us": round(1e3 * auto["kernel_ms"], 3),
+            "pivots_per_launch": int(pivots),
+            "algorithmic_bytes_per_launch": bytes_per_pivot * pivots,
+            "hbm_bytes_per_launch_by_construction": 2.0 * 8.0 * (m + 1) * (n + 1),
+            "note": "achieved = 16*m*(n+1) B x pivots of the launch / HIP-event time of the launch; the kernel "
+                    "reads the tableau from HBM once and writes it once per SOLVE, so the HBM traffic is "
+                    "1/pivots of the algorithmic bytes and the kernel is bound by the latency of the per-pivot "
+                    "hand-off, not by bandwidth; the HBM-streaming kernels are in roofline_rank1_update / rankj_update",
         }
     else:
-        achieved = bytes_per_pivot / (upd1_ms * 1e-3) / 1e9
-        roofline = {
-            "kernel": "k_simplex_update (rank-1 Gauss-Jordan update, one launch per pivot)",
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("k_simplex_update") if (m, n) == (512, 1024) else None,
-            "algorithmic_bytes_per_launch": bytes_per_pivot,
-        }
-    return out, roofline
+        roofline = dict(roofline_rank1)
+    return out, roofline, roofline_whole, roofline_rank1, rankj
 
 
 def batched_leg(ctx, args):
@@ -207,6 +256,9 @@ def cpu_baseline_leg(args):
     t0 = time.perf_counter()
     r = o.simplex_reference(A2, b2, c2, basis2, True, pn - pm, max_iter=piv, dense_eta_product=True)
     t_piv = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rt = o.simplex_tableau(A2, b2, c2, basis2, True, pn - pm)     # the SAME algorithm the GPU runs, 1 core
+    t_tab = time.perf_counter() - t0
     return {
         "value": round(sample / t_enum, 1), "unit": "subsets/s", "cores": 1, "kind": "port",
         "sample": f"oracle orc_enum_range on the first {sample} ranks of C({n},{m}) seed 0 "
@@ -215,6 +267,10 @@ def cpu_baseline_leg(args):
                   f"of m={pm} n={pn} in {t_piv:.1f} s",
         "simplex_pivots_per_s": round(r["iters"] / t_piv, 3),
         "simplex_equiv_GBs": round(16.0 * pm * (pn + 1) * r["iters"] / t_piv / 1e9, 4),
+        "simplex_same_algorithm_tableau_pivots_per_s": round(rt["iters"] / t_tab, 1),
+        "simplex_same_algorithm_tableau_solve_ms": round(1e3 * t_tab, 2),
+        "simplex_note": "two CPU baselines: the reference-SHAPED path (O(m^3) re-inversion per pivot, what the "
+                        "reference executes) and the tableau form the GPU executes (like-for-like algorithm)",
         "host_cores_available": os.cpu_count(),
         "note": "Eigen unavailable - restated baseline",
     }
@@ -318,15 +374,24 @@ def main():
                 "rank": res["rank"], "counts": res["counts"],
                 "kernel_ms_pass1_rank0": round(k_ms, 4),
                 "algorithmic_flops_per_subset": flops_per_subset,
-                "algorithmic_TFLOPs": round(value * flops_per_subset / 1e12, 3),
-                "frac_of_fp64_vector_peak": round(value * flops_per_subset / 1e12 /
-                                                  (FP64_VECTOR_PEAK_TF * world), 4),
+                "algorithmic_equiv_TFLOPs_no_frac": round(value * flops_per_subset / 1e12, 3),
+                # the shared-prefix kernels EXECUTE ~230 fp64 operations per subset (ISA count of
+                # k_enum_leaves), not the 3,243 an independent solve would need
+                "executed_fp64_ops_per_subset_estimate": 230,
+                "executed_TFLOPs_estimate": round(value * 230 / 1e12, 3),
+                "executed_frac_of_fp64_vector_peak": round(value * 230 / 1e12 / (FP64_VECTOR_PEAK_TF * world), 4),
+                "valu_issue_busy": (pmc_profile().get("enum_valu_issue_busy") if (m, n) == (16, 32) else None),
+                "mfma": "not used: per-subset row pivoting is data-dependent (DESIGN.md 4.6); no MFMA utilisation to report",
             },
         }
     if rank == 0 and not args.no_pivot:
-        pivot, roofline = pivot_leg(ctx, args)
+        pivot, roofline, roofline_whole, roofline_rank1, rankj = pivot_leg(ctx, args)
         line["pivot"] = pivot
         line["roofline"] = roofline
+        line["roofline_whole_pivot"] = roofline_whole
+        line["roofline_rank1_update"] = roofline_rank1
+        if rankj is not None:
+            line["rankj_update"] = rankj
     if rank == 0 and not args.no_batched:
         line["batched"] = batched_leg(ctx, args)
         line["two_phase"] = two_phase_leg(ctx, args)

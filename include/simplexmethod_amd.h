@@ -100,8 +100,9 @@ typedef struct lp_simplex_stats {
     int pivots;             /* pivots executed                                            */
     int launches;           /* kernel launches issued                                      */
     float solve_ms;         /* HIP-event time of the whole solve on the library's stream  */
-    float update_ms;        /* HIP-event time spent in rank-1 update launches (0 if not
-                               separately measurable for the chosen algorithm)            */
+    float update_ms;        /* HIP-event time spent in tableau-update launches: the rank-1 / rank-J
+                               update launches when lp_simplex_profile is on; for the chip-
+                               resident algorithm the one kernel that runs every pivot (always) */
     int update_launches;    /* launches counted in update_ms                               */
     double bytes_per_pivot; /* algorithmic bytes of one rank-1 update: 16*m*(n+1)          */
 } lp_simplex_stats;

@@ -131,6 +131,8 @@ void lp_simplex_free(lp_simplex_problem* p) {
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->res_ev0) (void)hipEventDestroy(p->res_ev0);
+    if (p->res_ev1) (void)hipEventDestroy(p->res_ev1);
     for (hipEvent_t e : p->upd_events) (void)hipEventDestroy(e);
     delete p;
 }
@@ -625,6 +627,10 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     {   // shared-prefix path: small control words, the feasible list, the pair table
         PrefixDev& pd = p->prefix;
         pd.list_cap = 1ULL << 22;
+        if (const char* e = getenv("LP_ENUM_LIST_CAP")) {   // tests: force the sub-range path on small problems
+            const unsigned long long v = strtoull(e, nullptr, 10);
+            if (v >= 64 && v < pd.list_cap) pd.list_cap = v;
+        }
         std::vector<unsigned short> pairtab((size_t)20 * kPairTabStride, 0);
         for (int R = 2; R < 20; ++R) {
             int r = 0;
@@ -707,6 +713,68 @@ static int check_range(lp_enum_problem* p, uint64_t begin, uint64_t end) {
     return LP_OPTIMAL;
 }
 
+// Shared-prefix enumeration of a range whose feasible subsets overflow the list: sub-ranges sized
+// from the feasible count the overflowing pass reported, split again where one still overflows.
+// Counts add, the best score is the maximum; every sub-range keeps its best score for pass 2.
+static int enum_prefix_chunked(lp_enum_problem* p, uint64_t begin, uint64_t end, uint64_t nfeas_hint,
+                               double* score_best, uint64_t counts[3], lp_enum_stats* stats) {
+    const uint64_t cap = p->prefix.list_cap;
+    p->pchunks.clear();
+    p->pchunks_valid = false;
+    struct Part { uint64_t b, e, hint; };
+    std::vector<Part> todo;
+    auto split = [&](uint64_t b, uint64_t e, uint64_t hint) {   // pushes in DEscending order (stack)
+        uint64_t parts = hint / (cap / 2) + 1;
+        if (parts < 2) parts = 2;
+        if (parts > e - b) parts = e - b;
+        for (uint64_t k = parts; k-- > 0;) {
+            const uint64_t pb = b + (e - b) / parts * k + std::min<uint64_t>(k, (e - b) % parts);
+            const uint64_t pe = b + (e - b) / parts * (k + 1) + std::min<uint64_t>(k + 1, (e - b) % parts);
+            todo.push_back({pb, pe, hint / parts + 1});
+        }
+    };
+    split(begin, end, nfeas_hint);
+    double best = -INFINITY;
+    float ms = 0.f;
+    int launches = 0;
+    for (int k = 0; k < 3; ++k) counts[k] = 0;
+    while (!todo.empty()) {
+        const Part part = todo.back();
+        todo.pop_back();
+        double sc = -INFINITY;
+        uint64_t cn[3] = {0, 0, 0};
+        lp_enum_stats st{};
+        int rc = lp_enum_prefix_range(p, part.b, part.e, &sc, cn, &st);
+        if (rc == kEnumListOverflow && part.e - part.b > 1) {
+            split(part.b, part.e, *p->h_list_count);
+            continue;
+        }
+        bool direct = false;
+        if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow) {   // no memory for the level buffers
+            rc = lp_enum_direct_range(p, part.b, part.e, &sc, cn, &st);
+            direct = true;
+        }
+        if (rc) return rc;
+        p->pchunks.push_back({part.b, part.e, sc, direct});
+        if (sc > best) best = sc;
+        for (int k = 0; k < 3; ++k) counts[k] += cn[k];
+        ms += st.kernel_ms;
+        launches += st.launches;
+    }
+    p->list_valid = false;
+    p->spec_valid = false;
+    p->pchunks_valid = true;
+    p->pchunks_begin = begin;
+    p->pchunks_end = end;
+    *score_best = best;
+    if (stats) {
+        stats->kernel_ms = ms;
+        stats->subsets = end - begin;
+        stats->launches = launches;
+    }
+    return LP_OPTIMAL;
+}
+
 int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, int algo,
                   double* zbest_out, uint64_t* counts_out, lp_enum_stats* stats_out) {
     if (!p) return LP_BAD_ARG;
@@ -718,6 +786,7 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     uint64_t counts[3] = {0, 0, 0};
     p->list_valid = false;
     p->spec_valid = false;
+    p->pchunks_valid = false;
     if (algo != LP_ENUM_ALGO_AUTO && algo != LP_ENUM_ALGO_DIRECT && algo != LP_ENUM_ALGO_PREFIX)
         LP_FAIL(ctx, LP_BAD_ARG, "unknown enumeration algorithm id");
     if (rank_begin == rank_end) {   // an empty shard (more processes than subsets): nothing to launch
@@ -735,8 +804,10 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
             if (!lp_enum_prefix_supported(p))
                 LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 16 and 2 <= n-m <= 16");
             rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
+            if (rc == kEnumListOverflow)   // more feasible subsets than the list holds: sub-ranges
+                rc = enum_prefix_chunked(p, rank_begin, rank_end, *p->h_list_count, &score, counts, stats_out);
             if (rc != LP_ITER_LIMIT) break;
-            // buffers or the feasible list were too small for this problem: direct path
+            // no memory for the level buffers of this problem: direct path
             [[fallthrough]];
         case LP_ENUM_ALGO_DIRECT:
             rc = lp_enum_direct_range(p, rank_begin, rank_end, &score, counts, stats_out);
@@ -765,6 +836,36 @@ int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_
             return LP_OPTIMAL;
         }
         return lp_enum_list_first(p, star, tol, rank_out);  // every feasible subset is listed
+    }
+    if (p->pchunks_valid && p->pchunks_begin == rank_begin && p->pchunks_end == rank_end) {
+        // the range was enumerated in sub-ranges (ascending): the first one that holds a qualifying
+        // subset is re-run to rebuild its list; the others are skipped on their best score
+        const std::vector<lp_enum_problem::PrefixChunk> chunks = p->pchunks;
+        *rank_out = UINT64_MAX;
+        for (const auto& ch : chunks) {
+            if (!(ch.best >= star - tol)) continue;
+            uint64_t first = UINT64_MAX;
+            if (ch.direct) {
+                rc = lp_enum_direct_first(p, ch.begin, ch.end, star, tol, &first);
+            } else {
+                double sc;
+                uint64_t cn[3];
+                rc = lp_enum_prefix_range(p, ch.begin, ch.end, &sc, cn, nullptr);
+                if (rc == LP_OPTIMAL) rc = lp_enum_list_first(p, star, tol, &first);
+                else if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow)
+                    rc = lp_enum_direct_first(p, ch.begin, ch.end, star, tol, &first);
+            }
+            if (rc) return rc;
+            if (first != UINT64_MAX) {
+                *rank_out = first;
+                break;
+            }
+        }
+        p->pchunks = chunks;   // (the re-runs do not disturb the record of the range pass)
+        p->pchunks_valid = true;
+        p->pchunks_begin = rank_begin;
+        p->pchunks_end = rank_end;
+        return LP_OPTIMAL;
     }
     return lp_enum_direct_first(p, rank_begin, rank_end, star, tol, rank_out);
 }

@@ -831,7 +831,8 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     }
     for (int t = 1; t <= D0; ++t)
         if (p->h_level_counts[t] > caps[t]) return LP_ITER_LIMIT;  // a level buffer was too small
-    if (*p->h_overflow != 0 || *p->h_list_count > pd.list_cap) return LP_ITER_LIMIT;  // fall back
+    if (*p->h_overflow != 0) return LP_ITER_LIMIT;  // fall back
+    if (*p->h_list_count > pd.list_cap) return kEnumListOverflow;   // the caller splits the range
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
     const uint64_t nfeas = *p->h_list_count;

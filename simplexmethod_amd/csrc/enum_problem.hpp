@@ -99,6 +99,17 @@ struct lp_enum_problem {
     bool list_valid = false;                   // the feasible list of the last prefix pass 1 is usable
     uint64_t list_begin = 0, list_end = 0, list_n = 0;
     int last_algo = 0;
+    // A range whose feasible subsets do not fit the list (degenerate LPs: up to every non-singular
+    // basis is feasible) is enumerated in sub-ranges, one list at a time; pass 2 re-runs only the
+    // sub-ranges whose best score can hold the winner.
+    struct PrefixChunk {
+        uint64_t begin, end;
+        double best;     // best score of the sub-range (-inf: no feasible subset)
+        bool direct;     // the sub-range ran on the direct kernel (no list)
+    };
+    std::vector<PrefixChunk> pchunks;
+    bool pchunks_valid = false;
+    uint64_t pchunks_begin = 0, pchunks_end = 0;
     // tie rule already applied on the device against the range's own best score (prefix path)
     bool spec_valid = false;
     double spec_star = 0.0, spec_tol = 0.0;
@@ -125,6 +136,9 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
 
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
-// LP_ITER_LIMIT = "could not run here (memory / list overflow), use the direct path"
+// LP_ITER_LIMIT = "could not run here (memory / a level buffer too small), use the direct path";
+// kEnumListOverflow = the feasible list was too small: *h_list_count holds the number of feasible
+// subsets of the range, the caller splits the range (capi.hip: enum_prefix_chunked)
+constexpr int kEnumListOverflow = 1001;
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
                          uint64_t counts[3], lp_enum_stats* stats);

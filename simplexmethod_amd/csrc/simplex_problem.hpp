@@ -73,6 +73,7 @@ struct lp_simplex_problem {
     SimplexState* h_state = nullptr;  // pinned
     std::vector<double> h_c;      // objective coefficients (Canonical::Evaluate on the host)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t res_ev0 = nullptr, res_ev1 = nullptr;   // around the chip-resident kernel launch
     std::vector<hipEvent_t> upd_events;  // 2 per timed rank-J update launch (look-ahead path)
     bool profile_updates = false;        // lp_simplex_profile: bracket update launches with events
     int init_status = LP_OPTIMAL; // LP_SINGULAR if the initial basis was singular

@@ -784,16 +784,23 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_resident_state_init, 1, 1, 0, s, d, eps, max_iter);
     LP_HIP(ctx, hipMemsetAsync(rd.comm, 0, rd.comm_bytes, s));   // every tag of every granule: epoch 0
+    if (!p->res_ev0) {   // HIP events tight around the one kernel launch (lp_simplex_stats::update_ms)
+        LP_HIP(ctx, hipEventCreate(&p->res_ev0));
+        LP_HIP(ctx, hipEventCreate(&p->res_ev1));
+    }
+    LP_HIP(ctx, hipEventRecord(p->res_ev0, s));
     if (stamped)
         hipLaunchKernelGGL((k_simplex_resident<RS_CPT, true>), rdv.G * rdv.stride, rdv.mpad, shm, s, d, rdv);
     else
         hipLaunchKernelGGL((k_simplex_resident<RS_CPT, false>), rdv.G * rdv.stride, rdv.mpad, shm, s, d, rdv);
+    LP_HIP(ctx, hipEventRecord(p->res_ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipEventSynchronize(p->ev1));
     LP_HIP(ctx, hipGetLastError());
-    float ms = 0.f;
+    float ms = 0.f, kms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    LP_HIP(ctx, hipEventElapsedTime(&kms, p->res_ev0, p->res_ev1));
     int status = p->h_state->status;
     if (status == kResidentFailed || status == kRunning) {
         // a hand-off timed out (e.g. the workgroups never became co-resident because another kernel
@@ -818,8 +825,8 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
         stats->pivots = p->h_state->iters;
         stats->launches = 2;
         stats->solve_ms = ms;
-        stats->update_ms = 0.f;
-        stats->update_launches = 0;
+        stats->update_ms = kms;         // the resident kernel alone: every pivot of the solve
+        stats->update_launches = 1;
         stats->bytes_per_pivot = 16.0 * (double)d.m * (double)(d.n + 1);
     }
     return status;

@@ -416,6 +416,33 @@ def test_vertices_against_the_reference_pinned_qr_solve(ctx, m, n):
     p.free()
 
 
+def test_feasible_list_spills_into_subranges(ctx, monkeypatch):
+    """Degenerate LPs (b = 0: every non-singular basis is feasible) overflow the feasible list of the
+    shared-prefix path; the range is then enumerated in sub-ranges, one list at a time, and pass 2
+    re-runs only the sub-range that holds the winner — never the direct kernel.  The list is shrunk
+    to 300 entries here so that small problems (oracle-checkable) take that path, including a
+    second-level split."""
+    monkeypatch.setenv("LP_ENUM_LIST_CAP", "300")
+    for seed, m, n, zero_rows in [(71, 8, 18, 8), (72, 8, 18, 5), (73, 10, 20, 10), (74, 7, 17, 0)]:
+        A, b, c, _ = lpcases.random_lp(seed, m, n)
+        b = b.copy()
+        b[:zero_rows] = 0.0
+        total = o.binom(n, m)
+        ref = o.enum_range(A, b, c, True, 0, total)
+        p = ctx.enum_problem(A, b, c, True)
+        got = p.range(0, total, capi.ENUM_PREFIX)[:3]
+        assert got == ref, (seed, m, n)
+        assert ref[2][0] > 300 or zero_rows == 0
+        k = p.first_within(0, total, ref[1])
+        assert k == o.enum_first_within(A, b, c, True, 0, total, ref[1])
+        # a sub-range of the rank space, and a second tolerance (served from the per-sub-range bests)
+        lo, hi = total // 7, total - total // 5
+        ref2 = o.enum_range(A, b, c, True, lo, hi)
+        assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref2
+        assert p.first_within(lo, hi, ref2[1], 1e-3) == o.enum_first_within(A, b, c, True, lo, hi, ref2[1], 1e-3)
+        p.free()
+
+
 def test_fuzz_small_structured_problems(ctx):
     """150 small problems with integer data in {-1, 0, 1, 2} (ties, zero pivots, duplicate columns
     everywhere), both senses: counts, optimum and the tie rule's rank against the oracle — on the
