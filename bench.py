@@ -217,6 +217,34 @@ def batched_leg(ctx, args):
     }
 
 
+def enum_inputs_leg(ctx, args):
+    """The enumeration's throughput depends on the data (wave-level early exit of infeasible
+    subsets, number of feasible bases): the headline seed next to three more seeds and to the worst
+    case for the feasible list, a fully degenerate LP (b = 0: every non-singular basis is feasible,
+    so the list overflows and the range is enumerated in sub-ranges).  One step = pass 1 + tie rule."""
+    from simplexmethod_amd import capi
+    m, n = args.enum_m, args.enum_n
+    out = []
+    for label, seed, degenerate in [("seed 1", 1, False), ("seed 2", 2, False), ("seed 3", 3, False),
+                                    ("seed 0 with b = 0 (fully degenerate)", 0, True)]:
+        A, b, c, _ = capi.gen_lp(seed, m, n)
+        if degenerate:
+            b = np.zeros_like(b)
+        p = ctx.enum_problem(A, b, c, True)
+        best, res = 1e9, None
+        for _ in range(1 if degenerate else 3):
+            t0 = time.perf_counter()
+            rc, z, counts, st = p.range(0, p.total, args.enum_algo)
+            k = p.first_within(0, p.total, z) if rc == 0 else None
+            best = min(best, time.perf_counter() - t0)
+            res = (rc, z, counts, k)
+        p.free()
+        out.append({"input": label, "ms_per_step": round(1e3 * best, 3),
+                    "subsets_per_s": round(p.total / best, 1), "status": int(res[0]),
+                    "optimum": res[1], "rank": res[3], "counts": res[2]})
+    return out
+
+
 def two_phase_leg(ctx, args):
     """a Symmetrical-style MIN problem (no starting basis) through
     lp_simplex_two_phase; host-buffer entry point, so the time includes both uploads."""
@@ -234,7 +262,8 @@ def two_phase_leg(ctx, args):
     return {
         "workload": f"min c.x, A0 x >= b, A0 {m}x{k} U(0,1) seed 0: canonical [A0|-I] {m}x{m + k}, no starting basis",
         "status": int(r["status"]), "pivots_phase1_driveout_phase2": r["iters"],
-        "crash_pivots_phase2": m, "ms_host_inclusive": round(best * 1e3, 3), "objective": r["obj"],
+        "phase2": "continues on the phase-I tableau (costs re-priced on the device, artificial columns barred)",
+        "ms_host_inclusive": round(best * 1e3, 3), "objective": r["obj"],
     }
 
 
@@ -316,27 +345,56 @@ def main():
     A, b, c, _ = capi.gen_lp(0, m, n)
     ep = ctx.enum_problem(A, b, c, True)
     total = ep.total
-    kernel_ms = []
+    my_bounds = lpdist.balanced_shard_bounds(n, m, rank, world)   # (what lp_enum_shard_bounds gives the C path)
+
+    # The exchange of the incumbent: the C ABI's own RCCL communicator (lp_comm_create_rccl +
+    # lp_enum_solve_sharded: ONE ncclAllGather of a 48-byte record per step) — the entry point a C++
+    # host uses.  torch.distributed only carries the 128-byte ncclUniqueId to the other ranks and
+    # the barriers / max-over-ranks of the timing.  If the communicator cannot be created on every
+    # rank, all ranks fall back together to the torch.distributed form of the same protocol
+    # (simplexmethod_amd/dist.py) and the line says so.
+    c_comm, exchange = None, "single participant (no collective)"
+    if world > 1:
+        ok = 0
+        if backend != "gloo":
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=reduce_device)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+                torch.distributed.broadcast(idt, src=0)
+                c_comm = capi.Comm.rccl(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+                ok = 1
+            except Exception as e:   # noqa: BLE001 - any failure means "use the other exchange"
+                print(f"[bench rank {rank}] C-ABI RCCL communicator unavailable: {e}", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int64, device=reduce_device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            exchange = "C ABI: lp_enum_solve_sharded over lp_comm_create_rccl (one ncclAllGather of 48 B per step)"
+        else:
+            if c_comm is not None:
+                c_comm.destroy()
+                c_comm = None
+            exchange = "torch.distributed (dist.py): one all_gather of the same record per step"
 
     def range_fn(lo, hi):
         rc, z, counts, st = ep.range(lo, hi, args.enum_algo)
-        kernel_ms.append(st.kernel_ms)
         return z, counts
 
     def first_fn(lo, hi, zstar, tol):
         return ep.first_within(lo, hi, zstar, tol)
 
-    # cost-balanced cut of the rank space (identical answer for any cut; see dist.py)
-    my_bounds = lpdist.balanced_shard_bounds(n, m, rank, world)
+    use_c = world == 1 or c_comm is not None
 
     def step():
+        if use_c:
+            r = ep.solve_sharded(c_comm, n - m)
+            return dict(feasible=r["status"] == 0, rank=r["rank"], counts=r["counts"], zstar=r["obj"])
         return lpdist.enum_solve_sharded(comm, total, True, range_fn, first_fn, bounds=my_bounds)
 
     for _ in range(args.warmup):
         res = step()
     comm.barrier()
     torch.cuda.synchronize()
-    kernel_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -350,7 +408,8 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = total * args.steps / elapsed
     flops_per_subset = (2.0 / 3.0) * m ** 3 + 2.0 * m ** 2
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    # kernel time of pass 1 on this rank's shard alone (outside the timed region)
+    k_ms = float(ep.range(my_bounds[0], my_bounds[1], args.enum_algo)[3].kernel_ms) if my_bounds[1] > my_bounds[0] else 0.0
     shard = my_bounds[1] - my_bounds[0]
 
     winner = ep.vertex(res["rank"], n - m) if res["feasible"] else None
@@ -368,6 +427,7 @@ def main():
                 "enum_algo": args.enum_algo, "subsets_per_gpu": shard,
                 "parallelism": f"cost-balanced rank-range shards x{world}, one all-gather of the "
                                "incumbent record (score, rank, counts) per step",
+                "exchange": exchange,
             },
             "enum": {
                 "optimum": None if winner is None else winner["obj"],
@@ -392,12 +452,17 @@ def main():
         line["roofline_rank1_update"] = roofline_rank1
         if rankj is not None:
             line["rankj_update"] = rankj
+    if rank == 0 and world == 1 and not args.no_batched:
+        line["enum"]["other_inputs"] = enum_inputs_leg(ctx, args)
+        line["enum"]["worst_case_subsets_per_s"] = min(r["subsets_per_s"] for r in line["enum"]["other_inputs"])
     if rank == 0 and not args.no_batched:
         line["batched"] = batched_leg(ctx, args)
         line["two_phase"] = two_phase_leg(ctx, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_leg(args)
     ep.free()
+    if c_comm is not None:
+        c_comm.destroy()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -238,6 +238,34 @@ int lp_enum_vertex(lp_enum_problem* p, uint64_t rank, int n_orig, double* x_out,
                    double* obj_out, int* verdict_out);
 void lp_enum_free(lp_enum_problem* p);
 
+/* ---- Enumeration sharded over the GPUs of a node (README.md:27,40-42) ------
+ * One participant per GPU — a process, or a host thread of one process — each with its own
+ * lp_context and its own lp_enum_problem (the tiny problem is replicated).  Participant `rank`
+ * of `world` enumerates shard lp_enum_shard_bounds(n, m, rank, world) with no data-path
+ * collective; the only exchange is ONE all-gather of a 48-byte record per participant (best
+ * score, smallest rank within 1e-9 of it, the three counts, status) — over RCCL/xGMI for
+ * lp_comm_create_rccl communicators.  A second all-gather happens only when two shards hold
+ * different vertices within 1e-9 of the optimum.  Results are identical on every participant and
+ * for every world size (tie rule).                                                            */
+typedef struct lp_comm lp_comm;
+/* 128 bytes (ncclUniqueId): one participant calls this and hands the bytes to the others (file,
+ * environment, MPI, a TCP store ...).  RCCL is loaded on first use (dlopen).                   */
+int lp_comm_unique_id(void* id_out_128_bytes);
+/* Collective: every participant calls it with the same id; blocks until all `world` have joined.
+ * The communicator is bound to ctx's device and stream.                                        */
+int lp_comm_create_rccl(lp_context* ctx, int rank, int world, const void* unique_id, lp_comm** comm_out);
+/* `world` communicators for host threads of ONE process, exchanging through host memory;
+ * participants may share a device (more shards than GPUs: what the one-GPU tests use).         */
+int lp_comm_create_local(int world, lp_comm** comms_out /* world entries */);
+int lp_comm_rank(const lp_comm* c);
+int lp_comm_world(const lp_comm* c);
+void lp_comm_destroy(lp_comm* c);
+/* comm == NULL: a single participant (no exchange).  Outputs as lp_enum_solve; counts_out[3] are
+ * the node-wide totals.  Every participant must call it (a failing one still takes part in the
+ * exchange, and every participant returns its status).                                          */
+int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double* x_out, int* basis_out,
+                          uint64_t* rank_out, double* obj_out, uint64_t* counts_out);
+
 #ifdef __cplusplus
 }
 #endif

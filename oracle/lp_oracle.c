@@ -388,6 +388,49 @@ static void tableau_pivot(double* T, int rows, int cols, int ld, int r, int e) {
     Tr[e] = 1.0;
 }
 
+/* The pivot loop of solveWithBasis (:429-450) on a tableau T ((m+1) x (n+1), row stride ld, rows by
+ * basis position, row m = reduced costs, column n = xB) whose basic columns are unit vectors.
+ * Columns j >= n_enter never enter the basis (phase II of the two-phase flow bars the artificial
+ * columns this way); n_enter = n is the plain solve.                                             */
+static int tableau_loop(double* T, int m, int n, int ld, int* N, int n_enter, int maximize, double eps,
+                        int max_iter, int* iteration_io, int* trace_enter, int* trace_leave, int trace_cap,
+                        unsigned char* nonbasic, unsigned char* rowmask, double* ratio) {
+    const int rows = m + 1, cols = n + 1;
+    int status = ORC_OPTIMAL;
+    int iteration = *iteration_io;
+    if (max_iter <= 0) status = ORC_ITER_LIMIT;
+    while (status == ORC_OPTIMAL) {
+        memset(nonbasic, 1, (size_t)n); /* complement :97-108 */
+        for (int t = 0; t < m; ++t) nonbasic[N[t]] = 0;
+        for (int j = n_enter; j < n; ++j) nonbasic[j] = 0;
+        double best;
+        const double* d = T + (size_t)m * ld;
+        int enter = orc_chain_select(d, nonbasic, n, maximize, eps, &best); /* :152-174 */
+        int optimal = maximize ? (best <= eps) : (best >= -eps);
+        if (optimal) break;
+        int any_pos = 0; /* :179 */
+        for (int i = 0; i < m; ++i) {
+            double ui = T[(size_t)i * ld + enter];
+            if (!(ui <= eps)) any_pos = 1;
+            rowmask[i] = (ui > eps);
+            ratio[i] = rowmask[i] ? T[(size_t)i * ld + n] / ui : 0.0; /* :186 */
+        }
+        if (!any_pos) { status = ORC_UNBOUNDED; break; }
+        int leave_pos = orc_chain_select(ratio, rowmask, m, 0, eps, NULL); /* :181-192 */
+        if (leave_pos < 0) { status = ORC_UNBOUNDED; break; }
+        if (iteration < trace_cap) {
+            if (trace_enter) trace_enter[iteration] = enter;
+            if (trace_leave) trace_leave[iteration] = leave_pos;
+        }
+        N[leave_pos] = enter; /* :196 */
+        tableau_pivot(T, rows, cols, ld, leave_pos, enter);
+        ++iteration;
+        if (iteration >= max_iter) { status = ORC_ITER_LIMIT; break; } /* :450 */
+    }
+    *iteration_io = iteration;
+    return status;
+}
+
 int orc_simplex_tableau(const double* A, int m, int n, const double* b, const double* c,
                         const int* basis_in, int maximize, int n_orig, double eps, int max_iter,
                         double* x_out, int* basis_out, double* obj_out, int* iters_out,
@@ -460,36 +503,9 @@ int orc_simplex_tableau(const double* A, int m, int n, const double* b, const do
     }
 
     int iteration = 0;
-    if (status == ORC_OPTIMAL) {
-        if (max_iter <= 0) status = ORC_ITER_LIMIT;
-        while (status == ORC_OPTIMAL) {
-            memset(nonbasic, 1, (size_t)n); /* complement :97-108 */
-            for (int t = 0; t < m; ++t) nonbasic[N[t]] = 0;
-            double best;
-            const double* d = T + (size_t)m * ld;
-            int enter = orc_chain_select(d, nonbasic, n, maximize, eps, &best); /* :152-174 */
-            int optimal = maximize ? (best <= eps) : (best >= -eps);
-            if (optimal) break;
-            int any_pos = 0; /* :179 */
-            for (int i = 0; i < m; ++i) {
-                double ui = T[(size_t)i * ld + enter];
-                if (!(ui <= eps)) any_pos = 1;
-                rowmask[i] = (ui > eps);
-                ratio[i] = rowmask[i] ? T[(size_t)i * ld + n] / ui : 0.0; /* :186 */
-            }
-            if (!any_pos) { status = ORC_UNBOUNDED; break; }
-            int leave_pos = orc_chain_select(ratio, rowmask, m, 0, eps, NULL); /* :181-192 */
-            if (leave_pos < 0) { status = ORC_UNBOUNDED; break; }
-            if (iteration < trace_cap) {
-                if (trace_enter) trace_enter[iteration] = enter;
-                if (trace_leave) trace_leave[iteration] = leave_pos;
-            }
-            N[leave_pos] = enter; /* :196 */
-            tableau_pivot(T, rows, cols, ld, leave_pos, enter);
-            ++iteration;
-            if (iteration >= max_iter) { status = ORC_ITER_LIMIT; break; } /* :450 */
-        }
-    }
+    if (status == ORC_OPTIMAL)
+        status = tableau_loop(T, m, n, ld, N, n, maximize, eps, max_iter, &iteration, trace_enter, trace_leave,
+                              trace_cap, nonbasic, rowmask, ratio);
 
     if (status == ORC_OPTIMAL) {
         double* x = (double*)xmalloc(sizeof(double) * (size_t)n);
@@ -565,9 +581,33 @@ int orc_two_phase(const double* A, int m, int n, const double* b, const double* 
         }
         free(basic);
     }
-    if (status == ORC_OPTIMAL) /* phase II from the clean basis, :383-404 */
-        status = orc_simplex_tableau(A1, m, n, b1, c, N, maximize, n_orig, eps, max_iter, x_out, N,
-                                     obj_out, &it[2], NULL, NULL, 0, NULL);
+    if (status == ORC_OPTIMAL) {
+        /* Phase II (:383-404) CONTINUES on the phase-I tableau instead of re-inverting the basis from
+         * [A' | b'] (what the reference's sketch does through computeBFS): the reduced-cost row is set
+         * to the original costs (0 for the artificial columns and the right-hand side) and priced out
+         * over the current basis with the crash step's arithmetic — m Gauss-Jordan pivots whose pivot
+         * elements are the 1s of the basic unit columns, so they only touch row m; the artificial
+         * columns stay in the tableau but never enter again.                                        */
+        const int ld = na + 1;
+        for (int j = 0; j <= na; ++j) T[(size_t)m * ld + j] = (j < n) ? c[j] : 0.0;
+        for (int t = 0; t < m; ++t) tableau_pivot(T, m + 1, na + 1, ld, t, N[t]);
+        unsigned char* nonbasic = (unsigned char*)xmalloc((size_t)na);
+        unsigned char* rowmask = (unsigned char*)xmalloc((size_t)m);
+        double* ratio = (double*)xmalloc(sizeof(double) * (size_t)m);
+        status = tableau_loop(T, m, na, ld, N, n, maximize, eps, max_iter, &it[2], NULL, NULL, 0, nonbasic,
+                              rowmask, ratio);
+        free(ratio); free(rowmask); free(nonbasic);
+        if (status == ORC_OPTIMAL) {
+            for (int j = 0; j < na; ++j) xa[j] = 0.0;
+            for (int t = 0; t < m; ++t) xa[N[t]] = T[(size_t)t * ld + na];
+            for (int j = 0; j < n_orig; ++j) x_out[j] = xa[j];
+            if (obj_out) { /* Canonical::Evaluate, Canonical.cpp:86 */
+                double z = 0.0;
+                for (int j = 0; j < n; ++j) z += c[j] * xa[j];
+                *obj_out = z;
+            }
+        }
+    }
     if (basis_out) memcpy(basis_out, N, sizeof(int) * (size_t)m);
     if (iters_out) memcpy(iters_out, it, sizeof(it));
     free(T); free(N); free(xa); free(c1); free(b1); free(A1);

@@ -45,7 +45,7 @@ def build_hip(force=False, verbose=False):
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
     extra = os.environ.get("LP_HIPCC_EXTRA", "").split()
-    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs
+    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs + ["-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -90,7 +90,7 @@ def build_cpp_tests(force=False, verbose=False):
         if force or not _newer(exe, deps):
             cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", HOST, "-I", TESTS_CPP,
                    "-o", exe, src, "-L", OUT, "-lsimplexmethod_host", "-lsimplexmethod_hip",
-                   "-pthread", "-Wl,-rpath," + OUT]
+                   "-pthread", "-Wl,-rpath,$ORIGIN/../../../simplexmethod_amd/_build"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

@@ -80,6 +80,13 @@ SIGNATURES = {
     "lp_enum_first_within": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _u64p]),
     "lp_enum_vertex": (C.c_int, [_vp, C.c_uint64, C.c_int, _dp, _ip, _dp, _ip]),
     "lp_enum_free": (None, [_vp]),
+    "lp_comm_unique_id": (C.c_int, [_vp]),
+    "lp_comm_create_rccl": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "lp_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "lp_comm_rank": (C.c_int, [_vp]),
+    "lp_comm_world": (C.c_int, [_vp]),
+    "lp_comm_destroy": (None, [_vp]),
+    "lp_enum_solve_sharded": (C.c_int, [_vp, _vp, C.c_int, _dp, _ip, _u64p, _dp, _u64p]),
 }
 
 _lib = None
@@ -415,6 +422,21 @@ class EnumProblem:
                                                          C.byref(r)))
         return int(r.value)
 
+    def solve_sharded(self, comm=None, n_orig=None):
+        """lp_enum_solve_sharded: this participant's shard of the rank space + the one exchange.
+        comm: a Comm (or None = single participant).  Blocks until every participant has called."""
+        n_orig = self.n if n_orig is None else n_orig
+        x = np.zeros(n_orig)
+        bo = np.zeros(self.m, dtype=np.int32)
+        rank = C.c_uint64(0)
+        obj = C.c_double(float("nan"))
+        counts = (C.c_uint64 * 3)()
+        rc = self.ctx.check(self.ctx.lib.lp_enum_solve_sharded(comm.h if comm is not None else None, self.h,
+                                                               n_orig, _d(x), _i(bo), C.byref(rank),
+                                                               C.byref(obj), counts))
+        return dict(status=rc, x=x, basis=bo, rank=int(rank.value), obj=obj.value,
+                    counts=[int(v) for v in counts])
+
     def vertex(self, rank, n_orig=None):
         n_orig = self.n if n_orig is None else n_orig
         x = np.zeros(n_orig)
@@ -435,3 +457,45 @@ class EnumProblem:
             self.free()
         except Exception:
             pass
+
+
+class Comm:
+    """lp_comm: the exchange of the sharded enumeration (one per participant)."""
+
+    def __init__(self, handle, lib):
+        self.h, self.lib = handle, lib
+
+    @staticmethod
+    def unique_id():
+        """128 bytes for Comm.rccl (rank 0 creates them and hands them to the other participants)."""
+        buf = C.create_string_buffer(128)
+        if load().lp_comm_unique_id(buf) != OPTIMAL:
+            raise LPError(BAD_ARG, "RCCL is not available (lp_comm_unique_id)")
+        return buf.raw
+
+    @staticmethod
+    def rccl(ctx, rank, world, unique_id):
+        """Collective: every participant calls it with the same id (ncclCommInitRank)."""
+        h = _vp()
+        ctx.check(ctx.lib.lp_comm_create_rccl(ctx.h, rank, world, C.c_char_p(unique_id), C.byref(h)))
+        return Comm(h, ctx.lib)
+
+    @staticmethod
+    def local(world):
+        """`world` communicators for host threads of this process (exchange through host memory)."""
+        lib = load()
+        arr = (_vp * world)()
+        if lib.lp_comm_create_local(world, arr) != OPTIMAL:
+            raise LPError(BAD_ARG, "lp_comm_create_local failed")
+        return [Comm(_vp(arr[r]), lib) for r in range(world)]
+
+    def rank(self):
+        return self.lib.lp_comm_rank(self.h)
+
+    def world(self):
+        return self.lib.lp_comm_world(self.h)
+
+    def destroy(self):
+        if self.h:
+            self.lib.lp_comm_destroy(self.h)
+            self.h = None

@@ -427,36 +427,32 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
         }
     }
     if (rc == LP_OPTIMAL) {
-        // replaceArtificialColumns (:331-381)
-        std::vector<double> trow((size_t)na + 1);
-        std::vector<unsigned char> basic((size_t)na);
-        for (int pos = 0; pos < m && rc == LP_OPTIMAL; ++pos) {
-            if (N[pos] < n) continue;
-            rc = lp_simplex_row(p, pos, trow.data());
-            if (rc) break;
-            std::fill(basic.begin(), basic.end(), (unsigned char)0);
-            for (int t = 0; t < m; ++t) basic[(size_t)N[t]] = 1;
-            int cand = -1;
-            for (int j = 0; j < n; ++j)
-                if (!basic[j] && std::fabs(trow[j]) > eps) {
-                    cand = j;
-                    break;
-                }
-            if (cand < 0) {
-                rc = LP_SINGULAR;  // :372-380: linearly dependent constraints
+        // replaceArtificialColumns (:331-381): every artificial still basic (at level 0) leaves for
+        // the first non-basic original column with |T[pos][cand]| > eps, chosen on the device; the
+        // positions are known from the phase-I basis, so all pivots are queued behind one another
+        std::vector<int> positions;
+        for (int pos = 0; pos < m; ++pos)
+            if (N[pos] >= n) positions.push_back(pos);
+        if (!positions.empty()) {
+            rc = lp_simplex_driveout(p, positions.data(), (int)positions.size(), n, eps, &it[1]);
+            if (rc == LP_SINGULAR)   // :372-380: linearly dependent constraints
                 ctx->last_error = "two-phase: an artificial variable cannot leave the basis (linearly dependent constraints)";
-                break;
-            }
-            rc = lp_simplex_force_pivot(p, pos, cand);
-            N[pos] = cand;
-            ++it[1];
         }
     }
+    // ---- phase II (:383-404) continues on the phase-I tableau: original costs priced out over the
+    // current basis, artificial columns barred — no re-inversion of the basis from [A' | b']
+    if (rc == LP_OPTIMAL) rc = lp_simplex_phase2_costs(p, c, n, maximize, n_orig);
+    if (rc == LP_OPTIMAL) {
+        rc = lp_simplex_run(p, eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
+        it[2] = st.pivots;
+        if (rc == LP_OPTIMAL)
+            rc = lp_simplex_download(p, x_out, N.data(), obj_out, nullptr, nullptr, 0, nullptr);
+        else if (rc > 0)
+            (void)lp_simplex_download(p, nullptr, N.data(), nullptr, nullptr, nullptr, 0, nullptr);
+    } else if (rc == LP_SINGULAR || rc == LP_INFEASIBLE) {
+        (void)lp_simplex_download(p, nullptr, N.data(), nullptr, nullptr, nullptr, 0, nullptr);
+    }
     lp_simplex_free(p);
-    // ---- phase II from the clean basis (:383-404)
-    if (rc == LP_OPTIMAL)
-        rc = lp_simplex_solve(ctx, A1.data(), m, n, b1.data(), c, N.data(), maximize, n_orig, eps, max_iter, x_out,
-                              N.data(), obj_out, &it[2]);
     if (basis_out) std::memcpy(basis_out, N.data(), sizeof(int) * (size_t)m);
     if (iters_out) std::memcpy(iters_out, it, sizeof(it));
     return rc;
@@ -745,7 +741,7 @@ static int enum_prefix_chunked(lp_enum_problem* p, uint64_t begin, uint64_t end,
         uint64_t cn[3] = {0, 0, 0};
         lp_enum_stats st{};
         int rc = lp_enum_prefix_range(p, part.b, part.e, &sc, cn, &st);
-        if (rc == kEnumListOverflow && part.e - part.b > 1) {
+        if (rc == kEnumListOverflow && part.e - part.b > 1 && *p->h_list_count * 2 <= part.e - part.b) {
             split(part.b, part.e, *p->h_list_count);
             continue;
         }
@@ -804,8 +800,16 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
             if (!lp_enum_prefix_supported(p))
                 LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 16 and 2 <= n-m <= 16");
             rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
-            if (rc == kEnumListOverflow)   // more feasible subsets than the list holds: sub-ranges
-                rc = enum_prefix_chunked(p, rank_begin, rank_end, *p->h_list_count, &score, counts, stats_out);
+            if (rc == kEnumListOverflow) {
+                // more feasible subsets than the list holds.  Every listed subset is re-solved for its
+                // objective, so once more than half of the range is feasible (a degenerate LP) the
+                // shared prefixes save nothing: that range goes to the direct kernel as a whole;
+                // otherwise it is enumerated in sub-ranges, one list at a time.
+                if (*p->h_list_count * 2 > rank_end - rank_begin)
+                    rc = LP_ITER_LIMIT;
+                else
+                    rc = enum_prefix_chunked(p, rank_begin, rank_end, *p->h_list_count, &score, counts, stats_out);
+            }
             if (rc != LP_ITER_LIMIT) break;
             // no memory for the level buffers of this problem: direct path
             [[fallthrough]];

@@ -285,6 +285,65 @@ __global__ __launch_bounds__(1024) void k_force_select(SimplexDev d, int row, in
     }
 }
 
+// Drive-out step of the two-phase flow (replaceArtificialColumns, SimplexSolover.h:331-381), chosen
+// ON THE DEVICE: the artificial basic at position `pos` leaves for the first non-basic column
+// j < n_limit with |T[pos][j]| > eps; none = linearly dependent constraints (sticky flag pad0).
+// Stages the pivot exactly as k_force_select does; k_simplex_update then applies it.
+__global__ __launch_bounds__(1024) void k_driveout_select(SimplexDev d, int pos, int n_limit, double eps) {
+    __shared__ int s_cand;
+    SimplexState* st = d.state;
+    const int tid = threadIdx.x, m = d.m, ld = d.ld;
+    if (tid == 0) {
+        s_cand = INT_MAX;
+        st->pivot_valid = 0;
+    }
+    __syncthreads();
+    if (st->pad0 != 0) return;   // an earlier position already failed
+    const double* trow = d.T + (size_t)pos * ld;
+    int mine = INT_MAX;
+    for (int j = tid; j < n_limit; j += blockDim.x)
+        if (d.nonbasic[j] && fabs(trow[j]) > eps) {
+            mine = j;
+            break;   // (ascending within the thread; the minimum over threads is the first overall)
+        }
+    if (mine != INT_MAX) atomicMin(&s_cand, mine);
+    __syncthreads();
+    const int col = s_cand;
+    if (col == INT_MAX) {
+        if (tid == 0) st->pad0 = 1;
+        return;
+    }
+    const double ur = trow[col];
+    for (int i = tid; i <= m; i += blockDim.x)
+        d.lcol[i] = (i == pos) ? 1.0 / ur : -d.T[(size_t)i * ld + col] / ur;
+    for (int j = tid; j < ld; j += blockDim.x) d.prow[j] = trow[j];
+    if (tid == 0) {
+        const int old = d.basis[pos];
+        d.basis[pos] = col;
+        d.nonbasic[col] = 0;
+        d.nonbasic[old] = 1;
+        st->enter = col;
+        st->leave = pos;
+        st->pivot_valid = 1;
+        st->pad1 += 1;   // drive-out pivots applied
+    }
+}
+__global__ void k_driveout_begin(SimplexDev d) {
+    d.state->pad0 = 0;
+    d.state->pad1 = 0;
+    d.state->pivot_valid = 0;
+}
+
+// Phase II on the phase-I tableau: row m <- the original costs (0 for the artificial columns and the
+// right-hand side); k_price_out_identity then prices it out over the current basis.  The artificial
+// columns are barred from entering by clearing their non-basic flag (none of them is basic any more).
+__global__ __launch_bounds__(256) void k_phase2_costs(SimplexDev d, const double* cost, int n_real) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > d.n) return;
+    d.T[(size_t)d.m * d.ld + j] = (j < n_real) ? cost[j] : 0.0;
+    if (j >= n_real && j < d.n) d.nonbasic[j] = 0;
+}
+
 // computeBFS for a basis whose columns are the unit vectors e_t in order but whose costs are not
 // zero (the artificial basis of a phase-I problem): the m crash pivots would have pivot element 1
 // and multipliers 0 on every constraint row, so all they do is eliminate the basic costs from the
@@ -380,6 +439,43 @@ int lp_simplex_force(lp_simplex_problem* p, int row, int col) {
 void lp_simplex_launch_update(lp_simplex_problem* p) {
     hipLaunchKernelGGL(k_simplex_update, update_grid(p->dev), dim3(UPD_TX, UPD_TY), 0,
                        p->ctx->stream, p->dev);
+}
+
+// Queues the drive-out of the artificial basics at the given positions; one host sync at the end.
+// Returns LP_OPTIMAL / LP_SINGULAR; *applied = pivots performed.
+int lp_simplex_driveout(lp_simplex_problem* p, const int* positions, int count, int n_limit, double eps,
+                        int* applied) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(k_driveout_begin, 1, 1, 0, s, d);
+    for (int k = 0; k < count; ++k) {
+        hipLaunchKernelGGL(k_driveout_select, 1, 1024, 0, s, d, positions[k], n_limit, eps);
+        lp_simplex_launch_update(p);
+    }
+    LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    LP_HIP(ctx, hipGetLastError());
+    if (applied) *applied = p->h_state->pad1;
+    return p->h_state->pad0 ? LP_SINGULAR : LP_OPTIMAL;
+}
+
+// Phase II continues on the current tableau with new costs (cost: n_real doubles on the host).
+int lp_simplex_phase2_costs(lp_simplex_problem* p, const double* cost, int n_real, int maximize, int n_orig) {
+    lp_context* ctx = p->ctx;
+    SimplexDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    LP_HIP(ctx, hipMemcpyAsync(p->dx, cost, sizeof(double) * (size_t)n_real, hipMemcpyHostToDevice, s));   // dx: n doubles of scratch
+    hipLaunchKernelGGL(k_phase2_costs, lp_ceil_div(d.n + 1, 256), 256, 0, s, d, (const double*)p->dx, n_real);
+    hipLaunchKernelGGL(k_price_out_identity, lp_ceil_div(d.n + 1, 256), 256, 0, s, d);
+    hipLaunchKernelGGL(k_price_out_commit, lp_ceil_div(d.n + 1, 256), 256, 0, s, d);
+    LP_HIP(ctx, hipStreamSynchronize(s));
+    LP_HIP(ctx, hipGetLastError());
+    d.maximize = maximize ? 1 : 0;
+    p->n_orig = n_orig;
+    p->h_c.assign((size_t)d.n, 0.0);
+    for (int j = 0; j < n_real; ++j) p->h_c[(size_t)j] = cost[j];
+    return LP_OPTIMAL;
 }
 
 int lp_simplex_price_out_identity(lp_simplex_problem* p) {

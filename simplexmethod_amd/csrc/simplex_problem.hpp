@@ -87,6 +87,8 @@ void lp_simplex_launch_update(lp_simplex_problem* p);
 int lp_simplex_crash(lp_simplex_problem* p);
 int lp_simplex_price_out_identity(lp_simplex_problem* p);  // unit-vector basis with non-zero costs
 int lp_simplex_force(lp_simplex_problem* p, int row, int col);  // host-chosen pivot on the current tableau
+int lp_simplex_driveout(lp_simplex_problem* p, const int* positions, int count, int n_limit, double eps, int* applied);
+int lp_simplex_phase2_costs(lp_simplex_problem* p, const double* cost, int n_real, int maximize, int n_orig);
 int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
 int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, float* ms_out);

@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -32,11 +33,16 @@ public:
     // Throws std::runtime_error("No feasible basis") when no basis is feasible.
     lpla::VectorXd solve() { return solve_ex().x; }
 
+    enum Exchange { EXCHANGE_AUTO = 0, EXCHANGE_RCCL = 1, EXCHANGE_LOCAL = 2 };
+
     // n_gpus > 1: the rank space is cut into n_gpus contiguous shards of equal estimated cost
-    // (lp_enum_shard_bounds), one host thread and one
-    // HIP device per shard; the incumbent is reduced on the host (a single process needs no
-    // RCCL — the one-process-per-GPU form over RCCL is simplexmethod_amd/dist.py).
-    Result solve_ex(int n_gpus = 1, bool throw_on_failure = true) {
+    // (lp_enum_shard_bounds), one host thread, one lp_context and one replica of the problem per
+    // shard; shard g runs on HIP device (device + g) % lp_device_count(), so a box with fewer GPUs
+    // than shards still exercises the sharded path.  The incumbent is exchanged by
+    // lp_enum_solve_sharded: ONE all-gather of a 48-byte record per shard — over RCCL/xGMI when every
+    // shard has a device of its own (EXCHANGE_AUTO), through host memory when shards share devices.
+    // The answer is identical for every n_gpus (tie rule of SURVEY.md 8 row E1).
+    Result solve_ex(int n_gpus = 1, bool throw_on_failure = true, Exchange exchange = EXCHANGE_AUTO) {
         const lpla::MatrixXd& A = _problem.GetConstraintsMatrix();
         const lpla::VectorXd& b = _problem.GetRightHandSide();
         const lpla::VectorXd& c = _problem.GetObjectiveCoefficients();
@@ -46,7 +52,7 @@ public:
         Result r;
         r.x = lpla::VectorXd::Zero(n_orig);
         r.basis.assign((size_t)m, -1);
-        if (n_gpus <= 1) {
+        if (n_gpus <= 1 && exchange != EXCHANGE_RCCL) {
             lp_context* ctx = lpgpu::context(_device);
             uint64_t counts[3] = {0, 0, 0};
             r.status = lp_enum_solve(ctx, A.data(), m, n, b.data(), c.data(), maximize, n_orig,
@@ -57,63 +63,77 @@ public:
             if (throw_on_failure) lpgpu::throw_for_status(r.status, ctx);
             return r;
         }
-        const uint64_t total = lp_binom(n, m);
-        if (total == 0) throw std::invalid_argument("C(n,m) does not fit 64 bits");
+        if (n_gpus < 1) n_gpus = 1;
+        if (lp_binom(n, m) == 0) throw std::invalid_argument("C(n,m) does not fit 64 bits");
+        const int ndev = lp_device_count();
+        if (ndev < 1) throw std::runtime_error("simplexmethod_amd: no HIP device (there is no CPU fallback)");
+        const bool rccl = exchange == EXCHANGE_RCCL || (exchange == EXCHANGE_AUTO && n_gpus <= ndev);
+        if (exchange == EXCHANGE_RCCL && n_gpus > ndev)
+            throw std::invalid_argument("RCCL exchange needs one device per shard");
         struct Shard {
             lp_context* ctx = nullptr;
             lp_enum_problem* p = nullptr;
-            uint64_t lo = 0, hi = 0, counts[3] = {0, 0, 0}, first = UINT64_MAX;
-            double z = 0.0;
+            lp_comm* comm = nullptr;
+            Result res;
             int rc = LP_OPTIMAL;
+            std::string error;
         };
         std::vector<Shard> sh((size_t)n_gpus);
-        for (int g = 0; g < n_gpus; ++g) {
-            sh[(size_t)g].ctx = lpgpu::context(_device + g);
-            if (lp_enum_shard_bounds(n, m, g, n_gpus, &sh[(size_t)g].lo, &sh[(size_t)g].hi) != LP_OPTIMAL)
-                throw std::invalid_argument("lp_enum_shard_bounds: bad problem shape");
+        std::vector<lp_comm*> local((size_t)n_gpus, nullptr);
+        unsigned char id[128] = {0};
+        if (rccl) {
+            if (lp_comm_unique_id(id) != LP_OPTIMAL) throw std::runtime_error("simplexmethod_amd: RCCL is not available");
+        } else if (lp_comm_create_local(n_gpus, local.data()) != LP_OPTIMAL) {
+            throw std::runtime_error("simplexmethod_amd: lp_comm_create_local failed");
         }
-        auto pass1 = [&](int g) {
+        auto run = [&](int g) {
             Shard& s = sh[(size_t)g];
-            s.rc = lp_enum_upload(s.ctx, A.data(), m, n, b.data(), c.data(), maximize, &s.p);
-            if (s.rc == LP_OPTIMAL)
-                s.rc = lp_enum_range(s.p, s.lo, s.hi, LP_ENUM_ALGO_AUTO, &s.z, s.counts, nullptr);
+            s.res.x = lpla::VectorXd::Zero(n_orig);
+            s.res.basis.assign((size_t)m, -1);
+            // a context (device binding + stream) of its own: shards may share a device
+            s.rc = lp_context_create((_device + g) % ndev, nullptr, &s.ctx);
+            if (s.rc == LP_OPTIMAL) s.rc = lp_enum_upload(s.ctx, A.data(), m, n, b.data(), c.data(), maximize, &s.p);
+            if (rccl) {   // collective: every thread joins, also one whose upload failed
+                lp_comm* cm = nullptr;
+                const int crc = s.ctx ? lp_comm_create_rccl(s.ctx, g, n_gpus, id, &cm) : LP_BAD_ARG;
+                if (s.rc == LP_OPTIMAL) s.rc = crc;
+                s.comm = cm;
+            } else {
+                s.comm = local[(size_t)g];
+            }
+            if (s.rc == LP_OPTIMAL) {
+                uint64_t counts[3] = {0, 0, 0};
+                s.rc = lp_enum_solve_sharded(s.comm, s.p, n_orig, s.res.x.data(), s.res.basis.data(), &s.res.rank,
+                                             &s.res.objective, counts);
+                s.res.feasible = counts[0];
+                s.res.infeasible = counts[1];
+                s.res.singular = counts[2];
+            }
+            if (s.rc != LP_OPTIMAL && s.ctx) s.error = lp_last_error(s.ctx);
+            s.res.status = s.rc;
         };
         std::vector<std::thread> th;
-        for (int g = 0; g < n_gpus; ++g) th.emplace_back(pass1, g);
+        for (int g = 0; g < n_gpus; ++g) th.emplace_back(run, g);
         for (auto& t : th) t.join();
-        bool any = false;
-        double zstar = 0.0;
+        int rc = LP_OPTIMAL;
+        std::string error;
+        for (auto& s : sh)   // the first failing shard decides (every shard fails together after the exchange)
+            if (s.rc != LP_OPTIMAL && rc == LP_OPTIMAL) {
+                rc = s.rc;
+                error = s.error;
+            }
+        r = sh[0].res;
+        r.status = rc;
         for (auto& s : sh) {
-            if (s.rc != LP_OPTIMAL && s.rc != LP_INFEASIBLE) {
-                for (auto& q : sh) lp_enum_free(q.p);
-                lpgpu::throw_for_status(s.rc, s.ctx);
-            }
-            r.feasible += s.counts[0];
-            r.infeasible += s.counts[1];
-            r.singular += s.counts[2];
-            if (s.rc == LP_OPTIMAL && (!any || (maximize ? s.z > zstar : s.z < zstar))) {
-                zstar = s.z;
-                any = true;
-            }
+            lp_enum_free(s.p);
+            lp_comm_destroy(s.comm);
+            lp_context_destroy(s.ctx);
         }
-        r.status = any ? LP_OPTIMAL : LP_INFEASIBLE;
-        if (any) {
-            th.clear();
-            auto pass2 = [&](int g) {
-                Shard& s = sh[(size_t)g];
-                if (s.rc == LP_OPTIMAL)
-                    (void)lp_enum_first_within(s.p, s.lo, s.hi, zstar, 1e-9, &s.first);
-            };
-            for (int g = 0; g < n_gpus; ++g) th.emplace_back(pass2, g);
-            for (auto& t : th) t.join();
-            uint64_t best = UINT64_MAX;
-            for (auto& s : sh) best = std::min(best, s.first);
-            r.rank = best;
-            int verdict = 0;
-            (void)lp_enum_vertex(sh[0].p, best, n_orig, r.x.data(), r.basis.data(), &r.objective, &verdict);
+        if (rc != LP_OPTIMAL && throw_on_failure) {
+            if (rc == LP_INFEASIBLE) throw std::runtime_error("No feasible basis");
+            if (rc == LP_BAD_ARG) throw std::invalid_argument("bad argument: " + error);
+            throw std::runtime_error("sharded enumeration failed (status " + std::to_string(rc) + "): " + error);
         }
-        for (auto& s : sh) lp_enum_free(s.p);
-        if (throw_on_failure) lpgpu::throw_for_status(r.status, sh[0].ctx);
         return r;
     }
 

@@ -416,6 +416,95 @@ def test_vertices_against_the_reference_pinned_qr_solve(ctx, m, n):
     p.free()
 
 
+def _solve_sharded_threads(A, b, c, maximize, n_orig, world, comms):
+    """One host thread per shard, each with a context and a replica of the problem of its own (they
+    share the one device of this box), all inside lp_enum_solve_sharded at the same time."""
+    import threading
+    out = [None] * world
+
+    def run(r):
+        cx = capi.Context(0)
+        p = cx.enum_problem(A, b, c, maximize)
+        try:
+            out[r] = p.solve_sharded(comms[r], n_orig)
+        except capi.LPError as e:
+            out[r] = e
+        p.free()
+        cx.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 6])
+def test_c_abi_sharded_solve_matches_oracle(ctx, world):
+    """lp_enum_solve_sharded (the C entry point a C++ host or bench.py --gpus N calls): shards of the
+    rank space, ONE all-gather of the incumbent record, identical answers on every participant and
+    for every world size — against the oracle's single-range solve.  Includes a problem with
+    duplicated columns (distinct bases, equal objective: the cross-shard tie rule) and one with no
+    feasible basis."""
+    cases = []
+    A, b, c, _ = lpcases.random_lp(21, 6, 14)
+    cases.append((A, b, c, True))
+    A2 = A.copy()
+    A2[:, 5] = A2[:, 1]                      # a duplicated column: tied vertices with different ranks
+    c2 = c.copy()
+    c2[5] = c2[1]
+    cases.append((A2, b, c2, True))
+    cases.append((A, b, c, False))
+    for A_, b_, c_, mx in cases:
+        m, n = A_.shape
+        ref = o.enum_solve(A_, b_, c_, mx, n - m)
+        comms = capi.Comm.local(world)
+        got = _solve_sharded_threads(A_, b_, c_, mx, n - m, world, comms)
+        for cm in comms:
+            cm.destroy()
+        for g in got:
+            assert not isinstance(g, Exception), g
+            assert g["status"] == ref["status"] == 0
+            assert g["rank"] == ref["rank"] and g["obj"] == ref["obj"] and g["counts"] == ref["counts"]
+            assert np.array_equal(g["x"], ref["x"]) and np.array_equal(g["basis"], ref["basis"])
+    # no feasible basis anywhere: every participant reports LP_INFEASIBLE
+    An = np.array([[1.0, 1.0, 1.0]])
+    comms = capi.Comm.local(world)
+    got = _solve_sharded_threads(An, [-1.0], [1.0, 1.0, 0.0], True, 2, world, comms)
+    for cm in comms:
+        cm.destroy()
+    assert all(g["status"] == capi.INFEASIBLE for g in got)
+
+
+def test_c_abi_sharded_solve_full_size_two_shards(ctx):
+    """C(28,14) in two cost-balanced shards through lp_enum_solve_sharded (shared-prefix kernels on
+    both shards at once on one device) against the single-range solve."""
+    A, b, c, _ = lpcases.random_lp(0, 14, 28)
+    one = ctx.enum_solve(A, b, c, True, 14)
+    comms = capi.Comm.local(2)
+    got = _solve_sharded_threads(A, b, c, True, 14, 2, comms)
+    for cm in comms:
+        cm.destroy()
+    for g in got:
+        assert g["rank"] == one["rank"] and g["obj"] == one["obj"] and g["counts"] == one["counts"]
+        assert np.array_equal(g["x"], one["x"])
+
+
+def test_c_abi_rccl_communicator(ctx):
+    """The RCCL backend of lp_comm with world = number of devices here (1 on the test box): librccl
+    loads (dlopen), ncclCommInitRank and the 48-byte ncclAllGather run on the library's stream."""
+    A, b, c, _ = lpcases.random_lp(22, 6, 13)
+    ref = o.enum_solve(A, b, c, True, 7)
+    comm = capi.Comm.rccl(ctx, 0, 1, capi.Comm.unique_id())
+    assert comm.rank() == 0 and comm.world() == 1
+    p = ctx.enum_problem(A, b, c, True)
+    g = p.solve_sharded(comm, 7)
+    p.free()
+    comm.destroy()
+    assert g["rank"] == ref["rank"] and g["obj"] == ref["obj"] and g["counts"] == ref["counts"]
+
+
 def test_feasible_list_spills_into_subranges(ctx, monkeypatch):
     """Degenerate LPs (b = 0: every non-singular basis is feasible) overflow the feasible list of the
     shared-prefix path; the range is then enumerated in sub-ranges, one list at a time, and pass 2

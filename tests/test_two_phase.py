@@ -13,7 +13,8 @@ def test_oracle_textbook_min():
     # min 2x1+3x2, x1+x2 >= 4, x1+3x2 >= 6: vertex (3,1), objective 9
     A = np.array([[1, 1, -1, 0], [1, 3, 0, -1.0]])
     r = o.two_phase(A, [4, 6.0], [2, 3, 0, 0.0], maximize=False, n_orig=2)
-    assert r["status"] == o.OPTIMAL and r["x"].tolist() == [3, 1] and r["obj"] == 9
+    # (phase II continues on the phase-I tableau, so the vertex carries phase I's rounding: 3 - 4e-16)
+    assert r["status"] == o.OPTIMAL and np.allclose(r["x"], [3, 1], rtol=0, atol=1e-12) and abs(r["obj"] - 9) <= 1e-12
     assert sorted(r["basis"].tolist()) == [0, 1]
 
 
@@ -26,7 +27,7 @@ def test_oracle_infeasible_dependent_negative_b():
     assert o.two_phase(A, [2, 2.0], [1, 2.0], maximize=False, n_orig=2)["status"] == o.SINGULAR
     # -x1-x2+s = -2 (make_b_nonneg, :61-68): min x1+2x2 -> (2,0)
     r = o.two_phase(np.array([[-1, -1, 1.0]]), [-2.0], [1, 2, 0.0], maximize=False, n_orig=2)
-    assert r["status"] == o.OPTIMAL and r["x"].tolist() == [2, 0] and r["obj"] == 2
+    assert r["status"] == o.OPTIMAL and np.allclose(r["x"], [2, 0], rtol=0, atol=1e-12) and abs(r["obj"] - 2) <= 1e-12
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -101,13 +102,17 @@ def test_gpu_golden(ctx):
 def test_gpu_known_cases(ctx):
     A = np.array([[1, 1, -1, 0], [1, 3, 0, -1.0]])
     g = ctx.two_phase(A, [4, 6.0], [2, 3, 0, 0.0], maximize=False, n_orig=2)
-    assert g["status"] == 0 and g["x"].tolist() == [3, 1] and g["obj"] == 9
+    # (phase II continues on the phase-I tableau: the vertex carries phase I's rounding, 3 - 4e-16;
+    # bit-exactness is against the oracle, below)
+    assert g["status"] == 0 and np.allclose(g["x"], [3, 1], rtol=0, atol=1e-12) and abs(g["obj"] - 9) <= 1e-12
+    r = o.two_phase(A, [4, 6.0], [2, 3, 0, 0.0], maximize=False, n_orig=2)
+    assert g["x"].tolist() == r["x"].tolist() and g["obj"] == r["obj"]
     A = np.array([[1, 1, 1, 0], [1, 1, 0, -1.0]])
     assert ctx.two_phase(A, [1, 3.0], [1, 1, 0, 0.0], maximize=False, n_orig=2)["status"] == o.INFEASIBLE
     A = np.array([[1, 1.0], [1, 1.0]])
     assert ctx.two_phase(A, [2, 2.0], [1, 2.0], maximize=False, n_orig=2)["status"] == o.SINGULAR
     g = ctx.two_phase(np.array([[-1, -1, 1.0]]), [-2.0], [1, 2, 0.0], maximize=False, n_orig=2)
-    assert g["status"] == 0 and g["x"].tolist() == [2, 0]
+    assert g["status"] == 0 and np.allclose(g["x"], [2, 0], rtol=0, atol=1e-12)
 
 
 @gpu
