@@ -17,6 +17,7 @@ struct BatchedDev {
     int* basis_out;         // batch x m  (by position)
     int* iters;             // batch
     int* status;            // batch
+    unsigned long long* stamps;   // diagnostic (LP_BATCHED_STAMPS=1): 16 per-phase cycle sums of workgroup 0; nullptr = off
 };
 
 // batched_simplex.hip

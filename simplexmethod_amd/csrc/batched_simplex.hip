@@ -27,160 +27,16 @@ namespace {
 
 constexpr int kRunning = -100;
 
-struct RedScratch {  // two alternating sets: a thread can be at most one reduction ahead
-    double v[2][16];
-    int a[2][16];
-    int b[2][16];
+struct Published {   // what wave 0 hands to the rest of the workgroup (first 16 bytes of LDS)
+    int v[4];        // [0] entering slot, [1] leaving position
 };
 
-struct Red {
-    RedScratch* sc;
-    int phase;
-    int lane, wave, nwaves;
-};
-
-// Block-wide extreme of lv; ties -> smallest key; payload slot.  Every thread calls.
-template <bool WANT_MAX>
-__device__ __forceinline__ void block_argext(Red& R, double lv, int lkey, int lslot, double& M,
-                                             int& key, int& slot) {
-    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
-    const double Mw = lpdev::wave_ext_f64<WANT_MAX>(lv);
-    const int kw = lpdev::wave_min_i32((lv == Mw && lv != sentinel) ? lkey : INT_MAX);
-    const unsigned long long hit = __ballot(lv == Mw && lkey == kw && kw != INT_MAX);
-    const int sw = hit ? __builtin_amdgcn_readlane(lslot, (int)__builtin_ctzll(hit)) : -1;
-    const int ph = R.phase;
-    R.phase ^= 1;
-    if (R.lane == 0) {
-        R.sc->v[ph][R.wave] = Mw;
-        R.sc->a[ph][R.wave] = kw;
-        R.sc->b[ph][R.wave] = sw;
-    }
-    __syncthreads();
-    M = sentinel;
-    key = INT_MAX;
-    slot = -1;
-    for (int w = 0; w < R.nwaves; ++w) {
-        const double v = R.sc->v[ph][w];
-        const int k = R.sc->a[ph][w];
-        const bool better = WANT_MAX ? (v > M) : (v < M);
-        if (k != INT_MAX && (better || (v == M && k < key))) {
-            M = v;
-            key = k;
-            slot = R.sc->b[ph][w];
-        }
-    }
-}
-
-template <bool WANT_MAX>
-__device__ __forceinline__ double block_ext(Red& R, double lv) {
-    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
-    const double Mw = lpdev::wave_ext_f64<WANT_MAX>(lv);
-    const int ph = R.phase;
-    R.phase ^= 1;
-    if (R.lane == 0) R.sc->v[ph][R.wave] = Mw;
-    __syncthreads();
-    double M = sentinel;
-    for (int w = 0; w < R.nwaves; ++w) M = lpdev::ext2<WANT_MAX>(M, R.sc->v[ph][w]);
-    return M;
-}
-
-// Block-wide minimum key with its value and slot (slow path jumps).
-__device__ __forceinline__ void block_minkey(Red& R, int lkey, double lval, int lslot, int& key,
-                                             double& val, int& slot) {
-    const int kw = lpdev::wave_min_i32(lkey);
-    const unsigned long long hit = __ballot(lkey == kw && kw != INT_MAX);
-    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
-    const double vw = lpdev::wave_bcast_f64(lval, src);
-    const int sw = __builtin_amdgcn_readlane(lslot, src);
-    const int ph = R.phase;
-    R.phase ^= 1;
-    if (R.lane == 0) {
-        R.sc->v[ph][R.wave] = vw;
-        R.sc->a[ph][R.wave] = kw;
-        R.sc->b[ph][R.wave] = sw;
-    }
-    __syncthreads();
-    key = INT_MAX;
-    val = 0.0;
-    slot = -1;
-    for (int w = 0; w < R.nwaves; ++w) {
-        const int k = R.sc->a[ph][w];
-        if (k < key) {
-            key = k;
-            val = R.sc->v[ph][w];
-            slot = R.sc->b[ph][w];
-        }
-    }
-}
-
-// The sequential EPS-hysteresis scan (SimplexSolover.h:153-161 / :164-172 / :181-192)
-// over `count` (value, key) entries stored in arbitrary order; entry s is read through
-// get(s, value, key, eligible).  Every thread of the block calls.  Returns the slot of the
-// selected entry (-1 if none) and the scan's final value in `best`.
-template <bool WANT_MAX, typename Get>
-__device__ int block_scan_keyed(Red& R, int count, double eps, double& best, Get get) {
-    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    double lv = sentinel;
-    int lkey = INT_MAX, lslot = -1;
-    for (int s = tid; s < count; s += nt) {
-        double v;
-        int k;
-        bool ok;
-        get(s, v, k, ok);
-        if (ok && ((WANT_MAX ? (v > lv) : (v < lv)) || (v == lv && k < lkey))) {
-            lv = v;
-            lkey = k;
-            lslot = s;
-        }
-    }
-    double M;
-    int jM, sM;
-    block_argext<WANT_MAX>(R, lv, lkey, lslot, M, jM, sM);
-    best = sentinel;
-    if (sM < 0) return -1;
-    double lp = sentinel;
-    for (int s = tid; s < count; s += nt) {
-        double v;
-        int k;
-        bool ok;
-        get(s, v, k, ok);
-        if (ok && k < jM) lp = lpdev::ext2<WANT_MAX>(lp, v);
-    }
-    const double P = block_ext<WANT_MAX>(R, lp);
-    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
-        best = M;
-        return sM;
-    }
-    // near-tie: replay the chain.  The next accepted entry is the one of smallest key among
-    // those beyond the threshold (entries before the current one cannot qualify again).
-    int sel = -1;
-    for (;;) {
-        const double thr = WANT_MAX ? best + eps : best - eps;
-        int ck = INT_MAX, cs = -1;
-        double cv = 0.0;
-        for (int s = tid; s < count; s += nt) {
-            double v;
-            int k;
-            bool ok;
-            get(s, v, k, ok);
-            if (ok && (WANT_MAX ? (v > thr) : (v < thr)) && k < ck) {
-                ck = k;
-                cv = v;
-                cs = s;
-            }
-        }
-        int key, slot;
-        double val;
-        block_minkey(R, ck, cv, cs, key, val, slot);
-        if (slot < 0) break;
-        best = val;
-        sel = slot;
-    }
-    return sel;
-}
-
-// The same scan done by ONE wave (the tableaus of this kernel have a few hundred rows/columns at
+// The sequential EPS-hysteresis scan (SimplexSolover.h:153-161 / :164-172 / :181-192) over `count`
+// (value, key) entries stored in arbitrary order; entry s is read through
+// get(s, value, key, eligible).  Returns the slot of the selected entry (-1 if none) and the scan's
+// final value in `best`.  Keys are the original indices: the scan order is ascending key.
+//
+// Done by ONE wave (the tableaus of this kernel have a few hundred rows/columns at
 // most: two or three entries per lane).  No LDS scratch, no barriers; the caller publishes the
 // result to the other waves.  Entries are re-read through get() on every pass.
 template <bool WANT_MAX, typename Get>
@@ -200,8 +56,10 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
             lslot = s;
         }
     }
-    const double M = lpdev::wave_ext_f64<WANT_MAX>(lv);
-    const int jM = lpdev::wave_min_i32((lv == M && lv != sentinel) ? lkey : INT_MAX);
+    // (reductions on sortable keys: device_select.hpp; lv / lp never hold a NaN — a NaN entry fails
+    // every comparison above and is never taken)
+    const double M = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lv)));
+    const int jM = (int)lpdev::wave_ext_u32<false>((unsigned)((lv == M && lv != sentinel) ? lkey : INT_MAX));
     best = sentinel;
     if (jM == INT_MAX) return -1;
     const unsigned long long hit = __ballot(lv == M && lkey == jM);
@@ -214,12 +72,12 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
         get(s, v, k, ok);
         if (ok && k < jM) lp = lpdev::ext2<WANT_MAX>(lp, v);
     }
-    const double P = lpdev::wave_ext_f64<WANT_MAX>(lp);
+    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lp)));
     if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
         best = M;
         return sM;
     }
-    // near-tie: replay the chain jump by jump (see block_scan_keyed)
+    // near-tie: replay the chain jump by jump (each jump: the eligible entry of smallest key beyond the threshold)
     int sel = -1;
     for (;;) {
         const double thr = WANT_MAX ? best + eps : best - eps;
@@ -236,7 +94,7 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
                 cs = s;
             }
         }
-        const int kmin = lpdev::wave_min_i32(ck);
+        const int kmin = (int)lpdev::wave_ext_u32<false>((unsigned)ck);
         if (kmin == INT_MAX) break;
         const int src = (int)__builtin_ctzll(__ballot(ck == kmin));
         best = lpdev::wave_bcast_f64(cv, src);
@@ -254,16 +112,16 @@ __device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, d
     double lext = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) lext = fmin(lext, rv[k]);
-    const double M = lpdev::wave_ext_f64<false>(lext);
+    const double M = lpdev::f64_from_key(lpdev::wave_ext_key<false>(lpdev::f64_sort_key(lext)));   // (fmin dropped NaNs)
     if (!(M < INFINITY)) return -1;
     int lidx = INT_MAX;
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) lidx = (rv[k] == M && lane + 64 * k < m) ? lane + 64 * k : lidx;
-    const int jM = lpdev::wave_min_i32(lidx);
+    const int jM = (int)lpdev::wave_ext_u32<false>((unsigned)lidx);
     double lp = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) lp = (lane + 64 * k < jM) ? fmin(lp, rv[k]) : lp;
-    const double P = lpdev::wave_ext_f64<false>(lp);
+    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<false>(lpdev::f64_sort_key(lp)));
     if (M < P - eps) return jM;
     // near-tie: replay the chain jump by jump
     double best = INFINITY;
@@ -278,7 +136,7 @@ __device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, d
                 cand = lane + 64 * k;
                 cv = rv[k];
             }
-        const int first = lpdev::wave_min_i32(cand);
+        const int first = (int)lpdev::wave_ext_u32<false>((unsigned)cand);
         if (first == INT_MAX) break;
         best = lpdev::wave_bcast_f64(cv, first & 63);
         sel = first;
@@ -286,14 +144,27 @@ __device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, d
     return sel;
 }
 
+// STAMPS (diagnostic build): cycles of every phase of a pivot as seen by wave 0 (the scanning wave)
+// and by wave 1 (an updating wave) of workgroup 0, summed in registers, stored once at the end.
+template <bool STAMPS>
 __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = STAMPS ? __builtin_readcyclecounter() : 0;
+#define BS_STAMP(s)                                                          \
+    do {                                                                     \
+        if (STAMPS) {                                                        \
+            const unsigned long long now_ = __builtin_readcyclecounter();    \
+            acc[(s)] += now_ - tprev;                                        \
+            tprev = now_;                                                    \
+        }                                                                    \
+    } while (0)
     const int m = d.m, n = d.n, nn = n - m, W = nn + 1, pitch = d.pitch;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lp = blockIdx.x;
     // ---- LDS carve
-    RedScratch* rs = reinterpret_cast<RedScratch*>(smem);
-    double* T = smem + sizeof(RedScratch) / 8;        // (m+1) x pitch
+    Published* pubs = reinterpret_cast<Published*>(smem);
+    double* T = smem + sizeof(Published) / 8;         // (m+1) x pitch
     double* prow = T + (size_t)(m + 1) * pitch;       // W
     double* lcol = prow + W;                          // m+1
     double* ratio = lcol + (m + 1);                   // m
@@ -333,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
     int iters = 0;
     int status = kRunning;
     const int wave = tid >> 6, lane = tid & 63;
-    int* pub = &rs->a[0][0];   // [0] entering slot, [1] leaving position, published by wave 0
+    int* pub = pubs->v;   // [0] entering slot, [1] leaving position, published by wave 0
     // Pricing over the non-basic slots, keyed by variable index (:152-174): wave 0 alone.  It runs
     // for pivot k+1 WHILE the other waves apply pivot k's update to the constraint rows: wave 0
     // updates the reduced-cost row first, which is all the pricing reads.
@@ -355,8 +226,11 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
     const int unt = nt - 64, ut = tid - 64;
     const int ugroups = unt / W > 0 ? unt / W : 1;
     if (wave == 0) price();
+    if (STAMPS) tprev = __builtin_readcyclecounter();
     while (true) {
+        BS_STAMP(0);       // wave 0: reduced-cost row + pricing; others: rank-1 update
         __syncthreads();   // tableau complete, pub[0] published
+        BS_STAMP(1);       // barrier wait
         if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
             status = LP_ITER_LIMIT;
             break;
@@ -401,7 +275,9 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
             }
             if (lane == 0) pub[1] = r;
         }
+        BS_STAMP(2);       // wave 0: entering column, ratios, ratio test
         __syncthreads();
+        BS_STAMP(3);       // barrier wait (the other waves wait here for the ratio test)
         const int r = pub[1];
         if (r < 0) {
             status = LP_UNBOUNDED;
@@ -413,7 +289,9 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
         for (int j = tid; j < W; j += nt) prow[j] = T[(size_t)r * pitch + j];
         for (int i = tid; i <= m; i += nt)
             lcol[i] = (i == r) ? inv : -T[(size_t)i * pitch + se] / ur;
+        BS_STAMP(4);       // eta column + pivot-row copy
         __syncthreads();
+        BS_STAMP(5);       // barrier wait
         // ---- rank-1 update of every stored element; slot se receives the leaving column
         if (wave == 0) {
             // the reduced-cost row, the basis bookkeeping, then the next pivot's pricing
@@ -467,6 +345,11 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
         d.iters[lp] = iters;
         d.status[lp] = status;
     }
+    if (STAMPS && d.stamps && lp == 0 && (tid == 0 || tid == 64)) {
+        for (int q = 0; q < 6; ++q) d.stamps[(tid ? 8 : 0) + q] = acc[q];
+        d.stamps[(tid ? 8 : 0) + 6] = (unsigned long long)iters;
+    }
+#undef BS_STAMP
 }
 
 }  // namespace
@@ -475,15 +358,21 @@ size_t lp_batched_lds_bytes(int m, int n, int* pitch_out) {
     const int nn = n - m, W = nn + 1;
     const int pitch = (W & 1) ? W : W + 1;  // odd pitch: conflict-free column reads
     if (pitch_out) *pitch_out = pitch;
-    size_t dbl = sizeof(RedScratch) / 8 + (size_t)(m + 1) * pitch + W + (m + 1) + m;
+    size_t dbl = sizeof(Published) / 8 + (size_t)(m + 1) * pitch + W + (m + 1) + m;
     size_t bytes = dbl * 8 + sizeof(int) * (size_t)(nn + m + n);
     return (bytes + 15) & ~(size_t)15;
 }
 
 int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
     const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);
-    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex),
+    if (d.stamps) {
+        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_batched_simplex<true>, d.batch, 1024, shm, ctx->stream, d);
+        return LP_OPTIMAL;
+    }
+    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_batched_simplex, d.batch, 1024, shm, ctx->stream, d);
+    hipLaunchKernelGGL(k_batched_simplex<false>, d.batch, 1024, shm, ctx->stream, d);
     return LP_OPTIMAL;
 }

@@ -554,7 +554,7 @@ void lp_enum_free(lp_enum_problem* p) {
     (void)hipFree(p->prefix.root_cursor);
     lp_pool_release(p->ctx, p->prefix.list, sizeof(unsigned long long) * p->prefix.list_cap);
     lp_pool_release(p->ctx, p->prefix.scores, sizeof(double) * p->prefix.list_cap);
-    (void)hipFree(p->prefix.list_count); (void)hipFree(p->dpairtab);
+    (void)hipFree(p->prefix.list_count);
     lp_pool_release(p->ctx, p->prefix.items, sizeof(int4) * (size_t)p->prefix.item_cap);
     lp_pool_release(p->ctx, p->prefix.items2, sizeof(int4) * (size_t)p->prefix.item_cap2);
     (void)hipFree(p->prefix.item_count);
@@ -620,18 +620,12 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
                           hipMemcpyHostToDevice, s));
-    {   // shared-prefix path: small control words, the feasible list, the pair table
+    {   // shared-prefix path: small control words, the feasible list
         PrefixDev& pd = p->prefix;
         pd.list_cap = 1ULL << 22;
         if (const char* e = getenv("LP_ENUM_LIST_CAP")) {   // tests: force the sub-range path on small problems
             const unsigned long long v = strtoull(e, nullptr, 10);
             if (v >= 64 && v < pd.list_cap) pd.list_cap = v;
-        }
-        std::vector<unsigned short> pairtab((size_t)20 * kPairTabStride, 0);
-        for (int R = 2; R < 20; ++R) {
-            int r = 0;
-            for (int qa = 0; qa < R; ++qa)
-                for (int qb = qa + 1; qb < R; ++qb) pairtab[(size_t)R * kPairTabStride + r++] = (unsigned short)(qa | (qb << 8));
         }
         LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
         LP_TRY(hipMalloc(&pd.item_count, 2 * sizeof(int)));
@@ -644,13 +638,9 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
             LP_TRY(lp_pool_alloc(ctx, (void**)&pd.scores, sizeof(double) * pd.list_cap, &got));
         }
         LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
-        LP_TRY(hipMalloc(&p->dpairtab, sizeof(unsigned short) * pairtab.size()));
         LP_TRY(hipHostMalloc(&p->h_level_counts, sizeof(int) * 32));
         LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
         LP_TRY(hipHostMalloc(&p->h_overflow, sizeof(int)));
-        LP_TRY(hipMemcpyAsync(p->dpairtab, pairtab.data(), sizeof(unsigned short) * pairtab.size(),
-                              hipMemcpyHostToDevice, s));
-        pd.pairtab = p->dpairtab;
         if (!ctx->dcomb6 || !ctx->dcomb5) {   // (shape-independent: once per context)
             // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
             std::vector<unsigned> comb6(32, 0u);
@@ -951,7 +941,7 @@ void lp_batched_free(lp_batched_problem* p) {
     for (auto* q : p->lps) lp_simplex_free(q);
     (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dx);
     (void)hipFree(p->dbasis_in); (void)hipFree(p->dbasis_out); (void)hipFree(p->diters);
-    (void)hipFree(p->dstatus);
+    (void)hipFree(p->dstatus); (void)hipFree(p->dev.stamps);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -1062,6 +1052,10 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
     if (p->resident) {
         p->dev.eps = eps;
         p->dev.max_iter = max_iter;
+        if (getenv("LP_BATCHED_STAMPS") && !p->dev.stamps) {   // diagnostic build of the kernel (scripts/stamp_batched.py)
+            LP_HIP(ctx, hipMalloc(&p->dev.stamps, sizeof(unsigned long long) * 16));
+            LP_HIP(ctx, hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 16));
+        }
         LP_HIP(ctx, hipEventRecord(p->ev0, ctx->stream));
         int rc = lp_batched_launch(ctx, p->dev);
         if (rc) return rc;
@@ -1071,6 +1065,16 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
         float ms = 0.f;
         LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
         if (ms_out) *ms_out = ms;
+        if (p->dev.stamps) {
+            unsigned long long h[16];
+            LP_HIP(ctx, hipMemcpy(h, p->dev.stamps, sizeof(h), hipMemcpyDeviceToHost));
+            const char* names[6] = {"reduced costs + pricing | rank-1 update", "barrier", "ratio test | (idle)", "barrier",
+                                    "eta column + pivot-row copy", "barrier"};
+            fprintf(stderr, "[batched stamps] workgroup 0, %llu pivots, %.3f ms: cycles per pivot, wave 0 | wave 1\n", h[6], ms);
+            for (int q = 0; q < 6; ++q)
+                fprintf(stderr, "[batched stamps]   %-42s %8.0f | %8.0f\n", names[q], (double)h[q] / (double)(h[6] ? h[6] : 1),
+                        (double)h[8 + q] / (double)(h[14] ? h[14] : 1));
+        }
         return LP_OPTIMAL;
     }
     float total = 0.f;

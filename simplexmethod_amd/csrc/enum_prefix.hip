@@ -14,15 +14,8 @@
 //            four 16-lane groups (lane = row) pivot four children at a time and write the child
 //            records; a block of 64 parents takes all its children's slots with one atomic.
 //            Narrow levels: one wave per (parent, child).  Bandwidth-shaped (7 GB for C(32,16)).
-//   phase 2  default: the leaf kernels of enum_leaf.hip (one lane per subset from the depth
+//   phase 2  the leaf kernels of enum_leaf.hip (one lane per subset from the depth
 //            m-7 records, with one or two more pivots done by the wave in LDS).
-//            LP_ENUM_SWEEP=1: k_enum_sweep (this file), an independent cooperative variant kept
-//            for cross-checking — one group per depth m-5 node, three more levels (m-5, m-4,
-//            m-3) in REGISTERS (lane = row, column slot = static register index; the pivot
-//            column is picked with a select chain, the pivot row is broadcast lane->group);
-//            depth m-2 nodes ("mu": two unused rows left) are written to LDS, and the last two
-//            columns are enumerated by ALL lanes of the workgroup, one lane per subset.  It
-//            shares more arithmetic but is latency-bound: > 10x slower than the leaf kernels.
 //   Feasible subsets are rare; their ranks are appended to a list and their objectives are
 //   evaluated afterwards by the direct solver (enum_direct.hip: k_enum_eval_list), which
 //   also serves pass 2 (tie rule) without a second enumeration.
@@ -38,12 +31,7 @@ namespace {
 
 using namespace lptree;
 
-constexpr int POOLC = 20;         // LDS columns (16 doubles each) per group for mu tableaus
-constexpr int MAXMU = 10;         // mu descriptors per group per round
-constexpr int SWEEP_THREADS = 256;
-constexpr int SWEEP_GROUPS = SWEEP_THREADS / PG;
 constexpr int kExpandParents = 64;  // parents per block of k_enum_expand (one slot allocation per block)
-constexpr int PAIRCAP = 3072;     // pair slots per workgroup round (16 groups x C(19,2)=171 max)
 
 // ---------------------------------------------------------------------------
 // phase 1: expand level t -> t+1 (records in HBM)
@@ -294,392 +282,6 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// phase 2: register-resident levels m-5, m-4, m-3; mu in LDS; pairs by all lanes
-// ---------------------------------------------------------------------------
-struct MuDesc {   // 48 bytes
-    unsigned long long rank_base;
-    double minp, maxp;
-    int colbase;   // first pool column (workgroup-wide index)
-    int R;         // remaining columns; column R of the mu block is the rhs
-    int r1, r2;    // the two unused rows
-    int pairbase;  // first slot of this mu's pairs in the round's pair list
-    int pad;
-};
-
-// P[ka] for a dynamic (group-uniform) ka: a chain of SP selects (a binary select tree on the
-// bits of ka was measured slower: more live registers for no shorter critical path).
-template <int SP>
-__device__ __forceinline__ double select_slot(const double (&P)[SP], int ka) {
-    double w = 0.0;
-#pragma unroll
-    for (int k = 0; k < SP; ++k)
-        if (k == ka) w = P[k];
-    return w;
-}
-
-// One Gauss-Jordan pivot on parent slot `ka` (dynamic, uniform in the group): child slot k-1
-// receives the transformed parent slot k for every k > ka.  Returns false if the subtree is
-// singular.  SP = parent slots.
-template <int SP>
-__device__ __forceinline__ bool pivot_level(const double (&P)[SP], double prhs, bool pused, int ka,
-                                            int m, int gl, int gbase, double pminp, double pmaxp,
-                                            double (&C)[SP - 1], double& crhs, bool& cused,
-                                            double& cminp, double& cmaxp) {
-    const double w = select_slot<SP>(P, ka);
-    double big;
-    const int p = pick_pivot_row(w, pused, gbase, big);
-    cminp = fmin(pminp, big);
-    cmaxp = fmax(pmaxp, big);
-    if (!(big > 0.0) || cminp <= DBL_EPSILON * (double)m * cmaxp) return false;
-    const int addr = (gbase + p) << 2;
-    const double piv = bcast16(w, addr);
-    const double inv = 1.0 / piv;
-    const bool isp = (gl == p);
-    // one fma per element: rows i != p take fma(l, pc, own); the pivot row takes pc*inv, written
-    // as fma(inv, pc, -0.0) (exactly the product, sign of zero included)
-    const double lx = isp ? inv : -(w * inv);
-    // columns in static blocks of four, skipped when no group of the wave needs them; inside a
-    // block nothing is predicated, so the broadcasts are issued back to back (dead columns of a
-    // group just receive values nobody reads)
-#pragma unroll
-    for (int kb = 1; kb < SP; kb += 4) {
-        if (__any(kb + 3 > ka)) {
-#pragma unroll
-            for (int k = kb; k < kb + 4 && k < SP; ++k) {
-                const double pc = bcast16(P[k], addr);
-                C[k - 1] = fma(lx, pc, isp ? -0.0 : P[k]);
-            }
-        }
-    }
-    const double pr = bcast16(prhs, addr);
-    crhs = fma(lx, pr, isp ? -0.0 : prhs);
-    cused = pused || isp;
-    return true;
-}
-
-// The same pivot with the parent read straight from its HBM record (depth D0 roots are not
-// kept in registers: a root is pivoted only once per ~4 depth m-3 nodes and stays L2-hot).
-template <int SP>
-__device__ __forceinline__ bool pivot_from_record(const double* __restrict__ P, int ncols, double prhs,
-                                                  bool pused, int ka, int m, int gl, int gbase,
-                                                  double pminp, double pmaxp, double (&C)[SP - 1],
-                                                  double& crhs, bool& cused, double& cminp,
-                                                  double& cmaxp) {
-    const double w = P[(size_t)ka * PG + gl];
-    double big;
-    const int p = pick_pivot_row(w, pused, gbase, big);
-    cminp = fmin(pminp, big);
-    cmaxp = fmax(pmaxp, big);
-    if (!(big > 0.0) || cminp <= DBL_EPSILON * (double)m * cmaxp) return false;
-    const int addr = (gbase + p) << 2;
-    const double piv = bcast16(w, addr);
-    const double inv = 1.0 / piv;
-    const bool isp = (gl == p);
-    const double lx = isp ? inv : -(w * inv);
-#pragma unroll
-    for (int kb = 1; kb < SP; kb += 4) {
-        if (__any(kb + 3 > ka)) {
-            double own[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kb + j;
-                own[j] = (k < SP && k < ncols) ? P[(size_t)k * PG + gl] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kb + j;
-                if (k < SP) {
-                    const double pc = bcast16(own[j], addr);
-                    C[k - 1] = fma(lx, pc, isp ? -0.0 : own[j]);
-                }
-            }
-        }
-    }
-    const double pr = bcast16(prhs, addr);
-    crhs = fma(lx, pr, isp ? -0.0 : prhs);
-    cused = pused || isp;
-    return true;
-}
-
-__global__ __launch_bounds__(SWEEP_THREADS, 2) void k_enum_sweep(EnumDev d, PrefixDev pd,
-                                                              const double* roots, int root_level,
-                                                              int root_cap, unsigned long long begin,
-                                                              unsigned long long end) {
-    const int nroots = min(pd.level_counts[root_level], root_cap);
-    constexpr int S5 = NMX + 5, S4 = NMX + 4, S3 = NMX + 3;
-    __shared__ __attribute__((aligned(16))) double s_pool[SWEEP_GROUPS * POOLC * PG];
-    __shared__ MuDesc s_desc[SWEEP_GROUPS * MAXMU];
-    __shared__ unsigned char s_pairmu[PAIRCAP];
-    __shared__ int s_npairs;
-
-    const int m = d.m, n = d.n, D0 = m - 5;
-    const int tid = threadIdx.x;
-    const int gl = tid & (PG - 1), grp = tid / PG;
-    const int lane = tid & 63, gbase = lane & ~(PG - 1);
-    const int lim5 = n - 5, lim4 = n - 4, lim3 = n - 3;  // largest child column per level
-
-    const double* rec5 = roots;  // record of the current depth-D0 root
-    double R4[S4];            // depth m-4 node, one register per selectable column
-    // depth m-3 node: NOT materialised (it would cost 38 more VGPRs and halve the occupancy);
-    // only its pivot (row address, multiplier) and rhs are kept, and its columns are
-    // re-derived from R4 with one extra fma where they are needed
-    int addr4 = 0;
-    double lx4 = 0.0;
-    bool isp4 = false;
-    double rhs4 = 0.0, rhs3 = 0.0;   // the root's rhs / min / max |pivot| are re-read from its record
-    bool used5 = true, used4 = true, used3 = true;
-    double minp4 = 0.0, maxp4 = 0.0, minp3 = 0.0, maxp3 = 0.0;
-    unsigned long long rb5 = 0, rb4 = 0, rb3 = 0;  // rank base of the NEXT child at each level
-    int a5 = 0, a4 = 0, a3 = 0;                    // last child column taken at each level
-    bool have5 = false, have4 = false, have3 = false, active = true;
-    unsigned int cntF = 0, cntI = 0, cntS = 0;        // per-lane (pair phase; far below 2^32 each)
-    unsigned long long cntSg = 0;                     // per-group (pruned singular subtrees)
-    __shared__ unsigned long long s_cnt[3];
-    if (tid < 3) s_cnt[tid] = 0ULL;
-
-    for (;;) {
-        if (tid == 0) s_npairs = 0;
-        __syncthreads();
-        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        if (pd.dbg) t0 = __builtin_readcyclecounter();
-        // ---------------- advance this group's walk to a depth m-3 node with children left.
-        // One such node per group per round: the four groups of a wave stay in step (all walk,
-        // then all produce); letting each group fill its pool from several nodes desynchronises
-        // them and serialises the wave (measured: 1.3x slower).
-        while (__any(active && !have3)) {
-            const bool need = active && !have3;
-            if (need && !have5) {
-                // roots are dealt dynamically (a static round-robin assignment was measured slower:
-                // subtree sizes differ too much)
-                int idx = 0;
-                if (gl == 0) idx = atomicAdd(pd.root_cursor, 1);
-                idx = __shfl(idx, 0, PG);
-                if (idx >= nroots) {
-                    active = false;
-                } else {
-                    const double* P = roots + (size_t)idx * rec_doubles(n, D0);
-                    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - D0 + 1));
-                    if (pm.last_col == kHole) continue;  // pruned slot (group-uniform)
-                    rec5 = P;
-                    used5 = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-                    rb5 = pm.rank_base;
-                    a5 = pm.last_col;
-                    have5 = true;
-                    have4 = false;
-                }
-            }
-            if (need && active && have5 && !have4) {
-                const int a = a5 + 1;
-                if (a > lim5) {
-                    have5 = false;
-                } else {
-                    const unsigned long long cnt = binom(d, n - 1 - a, 4);
-                    const unsigned long long ov = overlap(rb5, cnt, begin, end);
-                    if (ov != 0ULL) {
-                        const NodeMeta* pm5 = reinterpret_cast<const NodeMeta*>(rec5 + (size_t)PG * (n - D0 + 1));
-                        const double rhs5 = rec5[(size_t)(n - D0) * PG + gl];
-                        if (pivot_from_record<S5>(rec5, n - D0, rhs5, used5, a - D0, m, gl, gbase, pm5->minp,
-                                                  pm5->maxp, R4, rhs4, used4, minp4, maxp4)) {
-                            have4 = true;
-                            a4 = a;
-                            rb4 = rb5;
-                        } else {
-                            cntSg += ov;
-                        }
-                    }
-                    a5 = a;
-                    rb5 += cnt;
-                }
-            }
-            if (need && active && have4 && !have3) {
-                const int a = a4 + 1;
-                if (a > lim4) {
-                    have4 = false;
-                } else {
-                    const unsigned long long cnt = binom(d, n - 1 - a, 3);
-                    const unsigned long long ov = overlap(rb4, cnt, begin, end);
-                    if (ov != 0ULL) {
-                        const double w4 = select_slot<S4>(R4, a - (D0 + 1));
-                        double big4;
-                        const int p4 = pick_pivot_row(w4, used4, gbase, big4);
-                        minp3 = fmin(minp4, big4);
-                        maxp3 = fmax(maxp4, big4);
-                        if ((big4 > 0.0) && !(minp3 <= DBL_EPSILON * (double)m * maxp3)) {
-                            addr4 = (gbase + p4) << 2;
-                            const double inv4 = 1.0 / bcast16(w4, addr4);
-                            isp4 = (gl == p4);
-                            lx4 = isp4 ? inv4 : -(w4 * inv4);
-                            rhs3 = fma(lx4, bcast16(rhs4, addr4), isp4 ? -0.0 : rhs4);
-                            used3 = used4 || isp4;
-                            have3 = true;
-                            a3 = a;
-                            rb3 = rb4;
-                        } else {
-                            cntSg += ov;
-                        }
-                    }
-                    a4 = a;
-                    rb4 += cnt;
-                }
-            }
-        }
-        if (pd.dbg) t1 = __builtin_readcyclecounter();
-        // ---------------- produce mu nodes (depth m-2) of the current depth m-3 node into LDS
-        {
-            int poolused = 0, nmine = 0;
-            while (have3) {
-                const int a = a3 + 1;
-                if (a > lim3) {
-                    have3 = false;
-                    break;
-                }
-                const int Rmu = n - 1 - a;
-                if (poolused + Rmu + 1 > POOLC || nmine >= MAXMU) break;  // pool full: resume next round
-                const unsigned long long cnt = (unsigned long long)(Rmu * (Rmu - 1) / 2);
-                const unsigned long long ov = overlap(rb3, cnt, begin, end);
-                const unsigned long long rbmu = rb3;
-                a3 = a;
-                rb3 += cnt;
-                if (ov == 0ULL) continue;
-                const int ka = a - (D0 + 2);
-                // column a of the depth m-3 node = one fma on R4's column a (R3 slot ka = R4 slot ka+1)
-                const double w4c = select_slot<S4>(R4, ka + 1);
-                const double w = fma(lx4, bcast16(w4c, addr4), isp4 ? -0.0 : w4c);
-                double big;
-                const int p = pick_pivot_row(w, used3, gbase, big);
-                const double minp = fmin(minp3, big), maxp = fmax(maxp3, big);
-                if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
-                    cntSg += ov;
-                    continue;
-                }
-                const int addr = (gbase + p) << 2;
-                const double piv = bcast16(w, addr);
-                const double inv = 1.0 / piv;
-                const bool isp = (gl == p);
-                const double lx = isp ? inv : -(w * inv);
-                const int colbase = grp * POOLC + poolused;
-                double* pool = s_pool + (size_t)colbase * PG;
-#pragma unroll
-                for (int kb = 1; kb < S3; kb += 4) {
-                    if (__any(kb + 3 > ka)) {
-                        double v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int k = kb + j;
-                            if (k < S3) {
-                                const double r4 = R4[k + 1];
-                                const double r3 = fma(lx4, bcast16(r4, addr4), isp4 ? -0.0 : r4);
-                                const double pc = bcast16(r3, addr);
-                                v[j] = fma(lx, pc, isp ? -0.0 : r3);
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int k = kb + j;
-                            if (k < S3 && k > ka && k - ka - 1 < Rmu) pool[(k - ka - 1) * PG + gl] = v[j];
-                        }
-                    }
-                }
-                const double pr = bcast16(rhs3, addr);
-                pool[Rmu * PG + gl] = fma(lx, pr, isp ? -0.0 : rhs3);
-                const bool usedmu = used3 || isp;
-                const unsigned long long um = (__ballot(!usedmu) >> gbase) & 0xFFFFULL;
-                int base = 0;
-                if (gl == 0) {
-                    base = atomicAdd(&s_npairs, (int)cnt);
-                    MuDesc md;
-                    md.rank_base = rbmu;
-                    md.minp = minp;
-                    md.maxp = maxp;
-                    md.colbase = colbase;
-                    md.R = Rmu;
-                    md.r1 = um ? (int)__builtin_ctzll(um) : 0;
-                    const unsigned long long um2 = um & (um - 1);
-                    md.r2 = um2 ? (int)__builtin_ctzll(um2) : md.r1;
-                    md.pairbase = base;
-                    md.pad = 0;
-                    s_desc[grp * MAXMU + nmine] = md;
-                }
-                base = __shfl(base, 0, PG);
-                for (int r = gl; r < (int)cnt; r += PG)
-                    if (base + r < PAIRCAP) s_pairmu[base + r] = (unsigned char)(grp * MAXMU + nmine);
-                poolused += Rmu + 1;
-                ++nmine;
-            }
-        }
-        __syncthreads();
-        if (pd.dbg) t2 = __builtin_readcyclecounter();
-        const int npairs = s_npairs < PAIRCAP ? s_npairs : PAIRCAP;
-        // ---------------- pairs: one lane per subset (2x2 block + back-substitution)
-        for (int q = tid; q < npairs; q += SWEEP_THREADS) {
-            const int mi = s_pairmu[q];
-            const MuDesc md = s_desc[mi];
-            const int r = q - md.pairbase;
-            const unsigned pk = pd.pairtab[md.R * kPairTabStride + r];
-            const int qa = (int)(pk & 0xFF), qb = (int)(pk >> 8);
-            const double* colA = s_pool + (size_t)(md.colbase + qa) * PG;
-            const double* colB = s_pool + (size_t)(md.colbase + qb) * PG;
-            const double* colH = s_pool + (size_t)(md.colbase + md.R) * PG;
-            const double a1 = colA[md.r1], a2 = colA[md.r2];
-            const double b1 = colB[md.r1], b2 = colB[md.r2];
-            const double h1 = colH[md.r1], h2 = colH[md.r2];
-            const bool second = fabs(a2) > fabs(a1);
-            const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
-            const double qa_ = second ? a1 : a2, qb_ = second ? b1 : b2, qh = second ? h1 : h2;
-            const double big1 = fabs(pa);
-            const double inv1 = 1.0 / pa;
-            const double l = -(qa_ * inv1);
-            const double wqb = fma(l, pb, qb_);
-            const double rq = fma(l, ph, qh);
-            const double big2 = fabs(wqb);
-            const double inv2 = 1.0 / wqb;
-            const double xb = rq * inv2;
-            const double xa = fma(-pb, xb, ph) * inv1;
-            const double minp = fmin(md.minp, fmin(big1, big2));
-            const double maxp = fmax(md.maxp, fmax(big1, big2));
-            const bool sing = !(big1 > 0.0) || !(big2 > 0.0) || (minp <= DBL_EPSILON * (double)m * maxp);
-            bool feas = (xa >= -1e-9) && (xb >= -1e-9);
-#pragma unroll
-            for (int i = 0; i < PG; ++i) {
-                if (i < m && i != md.r1 && i != md.r2) {
-                    const double x = fma(-colB[i], xb, fma(-colA[i], xa, colH[i]));
-                    feas = feas && (x >= -1e-9);
-                }
-            }
-            const unsigned long long rank = md.rank_base + (unsigned long long)r;
-            if (rank >= begin && rank < end) {
-                if (sing) {
-                    ++cntS;
-                } else if (!feas) {
-                    ++cntI;
-                } else {
-                    ++cntF;
-                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-                    if (at < pd.list_cap) pd.list[at] = rank;
-                }
-            }
-        }
-        if (pd.dbg && tid == 0) {
-            t3 = __builtin_readcyclecounter();
-            atomicAdd(&pd.dbg[0], t1 - t0);
-            atomicAdd(&pd.dbg[1], t2 - t1);
-            atomicAdd(&pd.dbg[2], t3 - t2);
-            atomicAdd(&pd.dbg[3], 1ULL);
-            atomicAdd(&pd.dbg[4], (unsigned long long)npairs);
-        }
-        if (s_npairs > PAIRCAP && tid == 0) atomicExch(pd.overflow, 2);
-        if (!__syncthreads_or(active || have3)) break;
-    }
-    // ---------------- counts: block-level first, then one device atomic per counter
-    if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
-    if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
-    if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
-    if (gl == 0 && cntSg) atomicAdd(&s_cnt[2], cntSg);
-    __syncthreads();
-    if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -723,12 +325,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const EnumDev& d = p->dev;
     hipStream_t s = ctx->stream;
     const int m = d.m, n = d.n;
-    // default: breadth-first to depth m-6, then one lane per subset (enum_leaf.hip);
-    // LP_ENUM_SWEEP=1 selects the cooperative register-resident sweep from depth m-5 instead
-    const bool use_leaf = getenv("LP_ENUM_SWEEP") == nullptr;
+    // breadth-first to depth m-7 (m-6 for m = 6), then one lane per subset (enum_leaf.hip)
     // (the leaf kernel performs the pivot of depth m-6 itself, so the levels stop at depth m-7)
-    const bool fused = use_leaf && m >= 7;
-    const int D0 = use_leaf ? (fused ? m - 7 : m - 6) : m - 5;
+    const bool fused = m >= 7;
+    const int D0 = fused ? m - 7 : m - 6;
     PrefixDev& pd = p->prefix;
     // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0)
     const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
@@ -761,10 +361,6 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         p->prefix_buf_bytes[1] = got;
     }
     // depth-D0 records always end in buffer 0; levels alternate so that level D0 lands there
-    if (getenv("LP_ENUM_DEBUG") && !pd.dbg) {
-        LP_HIP(ctx, hipMalloc(&pd.dbg, 64));
-    }
-    if (pd.dbg) LP_HIP(ctx, hipMemsetAsync(pd.dbg, 0, 64, s));
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     int launches = 0;
     int cur = (D0 % 2 == 0) ? 0 : 1;  // buffer of level 0, so that level D0 is buffer 0
@@ -799,36 +395,21 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         cur = nxt;
     }
     const uint64_t root_bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, D0), 0x7FFFFFFFULL);
-    if (use_leaf) {
-        lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0,
-                              fused, lp_host_binom(n - m + D0 + 1, D0 + 1), begin, end);
-        ++launches;
-    } else {
-        // two workgroups per CU are resident (<= 256 VGPRs, 52 KB LDS each); a few more than that so
-        // that the tail is filled by the dynamic root dealing
-        const int grid = (int)std::min<uint64_t>(lp_ceil_div<uint64_t>(root_bound, SWEEP_GROUPS), (uint64_t)ctx->num_cus * 4);
-        hipLaunchKernelGGL(k_enum_sweep, grid, SWEEP_THREADS, 0, s, d, pd, p->prefix_buf[cur], D0, caps[D0],
-                           (unsigned long long)begin, (unsigned long long)end);
-        ++launches;
-    }
+    lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0,
+                          fused, lp_host_binom(n - m + D0 + 1, D0 + 1), begin, end);
+    ++launches;
     LP_HIP(ctx, hipMemcpyAsync(p->h_level_counts, pd.level_counts, sizeof(int) * 32, hipMemcpyDeviceToHost, s));
     // objectives of the (few) feasible subsets by the direct solver, and the tie rule against this
     // range's own best score (what a sharded run asks next): queued behind the leaf kernels
     constexpr double kSpecTol = 1e-9;   // Solver::EPS, the tolerance dist.py / EnumerationSolver use
     p->spec_valid = false;
-    if (use_leaf) lp_enum_queue_list_tail(p, kSpecTol);
+    lp_enum_queue_list_tail(p, kSpecTol);
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_overflow, pd.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipStreamSynchronize(s));
     LP_HIP(ctx, hipGetLastError());
-    if (pd.dbg) {
-        unsigned long long h[8];
-        LP_HIP(ctx, hipMemcpy(h, pd.dbg, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[enum_prefix] rounds %llu  cycles/round: advance %.0f produce %.0f pairs %.0f  pairs/round %.1f\n",
-                h[3], (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[3]);
-    }
     for (int t = 1; t <= D0; ++t)
         if (p->h_level_counts[t] > caps[t]) return LP_ITER_LIMIT;  // a level buffer was too small
     if (*p->h_overflow != 0) return LP_ITER_LIMIT;  // fall back
@@ -837,16 +418,11 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
     const uint64_t nfeas = *p->h_list_count;
     double best = -INFINITY;
-    if (use_leaf) {
-        if (nfeas) best = lp_key_f64(p->h_result->best_key);
-        p->spec_valid = true;
-        p->spec_star = best;
-        p->spec_tol = kSpecTol;
-        p->spec_first = nfeas ? p->h_result->first_rank : ~0ULL;
-    } else if (nfeas) {
-        int rc = lp_enum_eval_list(p, nfeas, &best);
-        if (rc) return rc;
-    }
+    if (nfeas) best = lp_key_f64(p->h_result->best_key);
+    p->spec_valid = true;
+    p->spec_star = best;
+    p->spec_tol = kSpecTol;
+    p->spec_first = nfeas ? p->h_result->first_rank : ~0ULL;
     p->list_valid = true;
     p->list_begin = begin;
     p->list_end = end;

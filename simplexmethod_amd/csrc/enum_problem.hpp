@@ -47,8 +47,6 @@ struct EnumDev {
     double* chunk_best;             // per-chunk best score of the last pass 1
 };
 
-constexpr int kPairTabStride = 192;  // >= C(19,2)
-
 // Shared-prefix path (enum_prefix.hip)
 struct PrefixDev {
     int* level_counts;                // [32]: records of each tree level (level 0 = 1), device side
@@ -58,7 +56,6 @@ struct PrefixDev {
     unsigned long long* list_count;
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
-    const unsigned short* pairtab;    // [R][r] -> (qa | qb << 8): r-th pair of R columns, lex order
     int4* items;                      // leaf-kernel work items, table 0: (record, child column, first subset, rank offset)
     int4* items2;                     // table 1 (two-level kernel): (record, child | j2 << 8, first subset, rank offset)
     int* item_count;                  // [2]
@@ -66,7 +63,6 @@ struct PrefixDev {
     const unsigned* comb5;            // same for 5-subsets (second level of the leaf kernel)
     const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
                                       // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]
-    unsigned long long* dbg;          // diagnostic cycle counters (nullptr = off): advance, produce, pairs, rounds
 };
 
 struct lp_enum_problem {
@@ -91,7 +87,6 @@ struct lp_enum_problem {
     PrefixDev prefix{};
     double* prefix_buf[2] = {nullptr, nullptr};
     size_t prefix_buf_bytes[2] = {0, 0};
-    unsigned short* dpairtab = nullptr;
     int* h_item_count = nullptr;               // pinned
     int* h_level_counts = nullptr;             // pinned copy of the 32 level counts
     unsigned long long* h_list_count = nullptr;  // pinned

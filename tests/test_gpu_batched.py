@@ -35,6 +35,20 @@ def test_batched_matches_oracle(ctx, m, n, count):
     _check(g, A, b, c, basis, True, n - m)
 
 
+def test_full_baseline_batch_4096(ctx):
+    """BASELINE.json configs[4] at its full size: 4096 LPs of m=128, n=256 (seeds 0..4095, what
+    bench.py times) — status, pivot count, basis, vertex and objective of EVERY LP bit-exact against
+    the oracle's tableau restatement (197,443 pivots; ~6 s of CPU)."""
+    batch, m, n = 4096, 128, 256
+    A = np.empty((batch, m, n)); b = np.empty((batch, m)); c = np.empty((batch, n))
+    basis = np.empty((batch, m), dtype=np.int32)
+    for k in range(batch):
+        A[k], b[k], c[k], basis[k] = capi.gen_lp(k, m, n)
+    g = ctx.simplex_solve_batched(A, b, c, basis, True, n - m)
+    assert (g["status"] == 0).all() and int(g["iters"].sum()) == 197443
+    _check(g, A, b, c, basis, True, n - m)
+
+
 def test_batched_minimise_unbounded_and_limit(ctx):
     A, b, c, basis = _batch(range(5), 12, 30)
     # minimise: the slack vertex is already optimal for c >= 0 (0 pivots) — and with negated

@@ -309,26 +309,6 @@ def test_prefix_rejects_unsupported_shapes(ctx):
     p.free()
 
 
-def test_prefix_sweep_variant_agrees(ctx, monkeypatch):
-    """LP_ENUM_SWEEP=1 selects the cooperative register-resident sweep (enum_prefix.hip) instead
-    of the one-lane-per-subset leaf kernel (enum_leaf.hip): same records, same bits."""
-    for m, n, seed in [(8, 20, 61), (10, 22, 62)]:
-        A, b, c, _ = lpcases.random_lp(seed, m, n)
-        total = o.binom(n, m)
-        p = ctx.enum_problem(A, b, c, True)
-        monkeypatch.delenv("LP_ENUM_SWEEP", raising=False)
-        leaf = p.range(0, total, capi.ENUM_PREFIX)[:3]
-        kleaf = p.first_within(0, total, leaf[1])
-        monkeypatch.setenv("LP_ENUM_SWEEP", "1")
-        sweep = p.range(0, total, capi.ENUM_PREFIX)[:3]
-        ksweep = p.first_within(0, total, sweep[1])
-        monkeypatch.delenv("LP_ENUM_SWEEP", raising=False)
-        st, z, counts = o.enum_range(A, b, c, True, 0, total)
-        assert leaf == sweep == (st, z, counts)
-        assert kleaf == ksweep == o.enum_first_within(A, b, c, True, 0, total, z)
-        p.free()
-
-
 # ---- BASELINE.json's full sizes: size-independent properties -----------------------------------
 
 @pytest.mark.parametrize("m,n", [(14, 28), (16, 32)])   # configs[2], configs[3]
