@@ -354,6 +354,331 @@ __global__ __launch_bounds__(1024) void k_batched_simplex(BatchedDev d) {
 
 }  // namespace
 
+// Pricing (:152-174) by one wave over up to 64*K entries held in REGISTERS: entry (lane + 64*q) has
+// value dv[q] and key kv[q] (the variable index: the scan order is ascending key; INT_MAX = no
+// entry).  Same chain semantics as wave_scan_keyed, without re-reading LDS on every pass.  Returns
+// the selected slot (-1 if none) and the scan's final value in `best`.
+template <bool WANT_MAX, int K>
+__device__ __forceinline__ int wave_price_select(const double (&dv)[K], const int (&kv)[K], double eps, double& best) {
+    const int lane = threadIdx.x & 63;
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    double lv = sentinel;
+    int lkey = INT_MAX, lslot = -1;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const bool ok = kv[q] != INT_MAX;
+        if (ok && ((WANT_MAX ? (dv[q] > lv) : (dv[q] < lv)) || (dv[q] == lv && kv[q] < lkey))) {
+            lv = dv[q];
+            lkey = kv[q];
+            lslot = lane + 64 * q;
+        }
+    }
+    const double M = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lv)));
+    const int jM = (int)lpdev::wave_ext_u32<false>((unsigned)((lv == M && lv != sentinel) ? lkey : INT_MAX));
+    best = sentinel;
+    if (jM == INT_MAX) return -1;
+    const unsigned long long hit = __ballot(lv == M && lkey == jM);
+    const int sM = __builtin_amdgcn_readlane(lslot, (int)__builtin_ctzll(hit));
+    double lp = sentinel;
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+        if (kv[q] < jM) lp = lpdev::ext2<WANT_MAX>(lp, dv[q]);
+    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lp)));
+    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+        best = M;
+        return sM;
+    }
+    int sel = -1;   // near-tie: replay the chain jump by jump
+    for (;;) {
+        const double thr = WANT_MAX ? best + eps : best - eps;
+        int ck = INT_MAX, cs = -1;
+        double cv = 0.0;
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+            if (kv[q] != INT_MAX && (WANT_MAX ? (dv[q] > thr) : (dv[q] < thr)) && kv[q] < ck) {
+                ck = kv[q];
+                cv = dv[q];
+                cs = lane + 64 * q;
+            }
+        const int kmin = (int)lpdev::wave_ext_u32<false>((unsigned)ck);
+        if (kmin == INT_MAX) break;
+        const int src = (int)__builtin_ctzll(__ballot(ck == kmin));
+        best = lpdev::wave_bcast_f64(cv, src);
+        sel = __builtin_amdgcn_readlane(cs, src);
+    }
+    return sel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident form of the same kernel (what lp_batched_launch selects when the shape fits):
+// the constraint rows of the condensed tableau live in REGISTERS.  Updating thread (column j, row
+// group g) owns rows g, g + G, g + 2G, ... of column j for the whole solve — the assignment the
+// LDS kernel above already uses, so nothing about the arithmetic changes — and LDS only carries
+// what has to cross threads: the entering column and xB (read by wave 0's ratio test), the eta
+// column, the pivot row and the reduced-cost row.  Per pivot the LDS kernel moves the whole
+// tableau through LDS three times (400 KB at 128 x 256: 7.4 k of its 10.4 k cycles,
+// profiles/r02_batched_stamps.txt); here a thread reads RPT eta entries (broadcast) and does RPT
+// fused multiply-adds.  Bit-identical results (same operands, same operations per element).
+// ---------------------------------------------------------------------------------------------
+// Rows are padded to G * RPT: entries past m hold zeros in the eta column (fma(0, p, 0) = 0), so the
+// per-row loops carry no predicates (44 live lane masks would spill ~600 SGPRs).
+template <int NT>
+__host__ __device__ inline int batched_reg_rpt(int m, int n) {   // rows per updating thread, 0 = does not fit
+    const int W = n - m + 1;
+    if (W < 2 || W > NT - 64) return 0;
+    const int G = (NT - 64) / W;
+    return (m + G - 1) / G;
+}
+
+// (NT = 512 asks for 4 waves per SIMD = two workgroups per CU: two LPs share a CU, and one LP's
+// one-wave scans run under the other's update)
+// DREG: wave 0 keeps the reduced-cost row in registers (12 more VGPRs: not in the 512-thread form,
+// whose 128-VGPR budget is already short).
+template <int NT, int RPT, bool DREG>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(BatchedDev d) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = d.m, n = d.n, nn = n - m, W = nn + 1;
+    const int tid = threadIdx.x;
+    const int lp = blockIdx.x;
+    const int G = (NT - 64) / W;
+    const int mp = G * RPT;                           // padded row count (>= m)
+    // ---- LDS carve
+    Published* pubs = reinterpret_cast<Published*>(smem);
+    double* drow = smem + sizeof(Published) / 8;      // W    : reduced-cost row (entry nn = -objective)
+    double* prow = drow + W;                          // W    : pivot row before scaling
+    double* lcol = prow + W;                          // mp+1 : eta column (entry mp: reduced-cost row), zeros past m
+    double* ucol = lcol + (mp + 1);                   // mp   : entering column
+    double* xcol = ucol + mp;                         // mp   : xB
+    int* slotvar = reinterpret_cast<int*>(xcol + mp); // nn   : variable held by each slot
+    int* basis = slotvar + nn;                        // m    : N by position
+    int* posofvar = basis + m;                        // n    : scratch for the initial split
+
+    const double* A = d.A + (size_t)lp * m * n;
+    const double* b = d.b + (size_t)lp * m;
+    const double* c = d.c + (size_t)lp * n;
+    const int* bin = d.basis_in + (size_t)lp * m;
+
+    // ---- initial condensed tableau for the slack identity basis (Symmetrical.cpp:169-188)
+    for (int q = tid; q < n; q += NT) posofvar[q] = -1;
+    for (int q = tid; q <= mp; q += NT) lcol[q] = 0.0;
+    __syncthreads();
+    for (int q = tid; q < m; q += NT) {
+        basis[q] = bin[q];
+        posofvar[bin[q]] = q;
+    }
+    __syncthreads();
+    if (tid == 0) {  // slots take the non-basic variables in ascending order
+        int s = 0;
+        for (int q = 0; q < n; ++q)
+            if (posofvar[q] < 0) slotvar[s++] = q;
+    }
+    __syncthreads();
+    // updating threads: tid >= 64; column j, row group g of G; rows g*RPT .. g*RPT + RPT-1 (a contiguous
+    // block: the k-th row is a compile-time offset from one LDS address per array)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ut = tid - 64;
+    const int j = ut >= 0 ? ut % W : 0;
+    const int g = ut >= 0 ? ut / W : G;
+    const bool upd = ut >= 0 && g < G;
+    double t[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int i = g * RPT + k;
+        t[k] = (upd && i < m) ? ((j < nn) ? A[(size_t)slotvar[j] * m + i] : b[i]) : 0.0;
+    }
+    for (int q = tid; q < mp; q += NT) {
+        xcol[q] = q < m ? b[q] : 0.0;
+        ucol[q] = 0.0;
+    }
+    for (int q = tid; q < nn; q += NT) drow[q] = c[slotvar[q]];
+    if (tid == 0) drow[nn] = 0.0;
+    __syncthreads();
+
+    const double eps = d.eps;
+    int iters = 0;
+    int status = kRunning;
+    int* pub = pubs->v;   // [0] entering slot, [1] leaving position, published by wave 0
+    // Pricing over the non-basic slots, keyed by variable index (:152-174): wave 0 alone, for pivot
+    // k+1 WHILE the other waves apply pivot k's update to their registers.  For nn <= 256 wave 0 keeps
+    // the reduced-cost row and the slots' keys in REGISTERS (entry lane + 64*q), so a pivot's pricing
+    // reads no LDS but the pivot row; LDS drow[] then only carries the entering slot's value (the
+    // -objective entry of the row is not kept: the objective is evaluated from the vertex on the host).
+    const bool dreg = DREG && nn <= 256;
+    double dv[4] = {0.0, 0.0, 0.0, 0.0};
+    int kv[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    if (wave == 0 && dreg) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = lane + 64 * q;
+            if (sl < nn) {
+                dv[q] = drow[sl];
+                kv[q] = slotvar[sl];
+            }
+        }
+    }
+    auto price = [&]() {
+        double best;
+        int se0;
+        if (dreg) {
+            se0 = d.maximize ? wave_price_select<true, 4>(dv, kv, eps, best)
+                             : wave_price_select<false, 4>(dv, kv, eps, best);
+        } else {
+            auto getd = [&](int sl, double& v, int& k, bool& ok) {
+                v = drow[sl];
+                k = slotvar[sl];
+                ok = true;
+            };
+            se0 = d.maximize ? wave_scan_keyed<true>(nn, eps, best, getd)
+                             : wave_scan_keyed<false>(nn, eps, best, getd);
+        }
+        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);
+        if (optimal) se0 = -1;
+        if (dreg && se0 >= 0) {   // the entering slot's reduced cost, for the eta column's entry of row m
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane + 64 * q == se0) drow[se0] = dv[q];
+        }
+        if (lane == 0) pub[0] = se0;
+    };
+    if (wave == 0) price();
+    while (true) {
+        __syncthreads();   // registers and xcol complete, pub[0] published
+        if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
+            status = LP_ITER_LIMIT;
+            break;
+        }
+        const int se = pub[0];
+        if (se < 0) {
+            status = LP_OPTIMAL;
+            break;
+        }
+        // ---- the entering column leaves its owners' registers (:176)
+        if (upd && j == se) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
+        }
+        __syncthreads();
+        // ---- unbounded test (:179), ratios (:185-186) and the ratio test keyed by basis position
+        // (:181-194; +inf entries are never taken): wave 0 alone
+        if (wave == 0) {
+            int r;
+            if (m <= 256) {
+                double rv[4];
+                int any_pos = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = lane + 64 * k;
+                    const double ui = (i < m) ? ucol[i] : 0.0;
+                    rv[k] = (i < m && ui > eps) ? xcol[i] / ui : INFINITY;
+                    if (i < m && !(ui <= eps)) any_pos = 1;
+                }
+                r = wave_ratio_select<4>(rv, m, eps);
+                if (!__any(any_pos)) r = -1;
+            } else {
+                int any_pos = 0;
+                for (int i = lane; i < m; i += 64)
+                    if (!(ucol[i] <= eps)) any_pos = 1;
+                double theta;
+                auto getr = [&](int i, double& v, int& k, bool& ok) {
+                    const double ui = ucol[i];
+                    v = (ui > eps) ? xcol[i] / ui : INFINITY;
+                    k = i;
+                    ok = true;
+                };
+                r = wave_scan_keyed<false>(m, eps, theta, getr);
+                if (!__any(any_pos)) r = -1;
+            }
+            if (lane == 0) pub[1] = r;
+        }
+        __syncthreads();
+        const int r = pub[1];
+        if (r < 0) {
+            status = LP_UNBOUNDED;
+            break;
+        }
+        // ---- eta column (:198-204) and the pivot row, from the owners' registers
+        const double ur = ucol[r];
+        const double inv = 1.0 / ur;
+        for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
+        if (tid == 0) lcol[mp] = -drow[se] / ur;
+        const int gr = r / RPT, kr = r % RPT;
+        if (upd && g == gr) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                if (k == kr) prow[j] = t[k];
+        }
+        __syncthreads();
+        // ---- rank-1 update; slot se receives the leaving column (the eta column itself)
+        if (wave == 0) {
+            // the reduced-cost row, the basis bookkeeping, then the next pivot's pricing
+            const double lm = lcol[mp];
+            const int vleave = basis[r];
+            if (dreg) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = lane + 64 * q;
+                    if (sl < nn) {
+                        dv[q] = (sl == se) ? lm : fma(lm, prow[sl], dv[q]);
+                        if (sl == se) kv[q] = vleave;   // slot se now holds the leaving variable
+                    }
+                }
+            } else {
+                for (int q = lane; q < W; q += 64) drow[q] = (q == se) ? lm : fma(lm, prow[q], drow[q]);
+            }
+            if (lane == 0) {
+                const int ve = slotvar[se];
+                slotvar[se] = vleave;
+                basis[r] = ve;  // N(leave_pos) = enter, :196
+            }
+            price();
+        } else if (upd) {
+            const double pj = prow[j];
+            if (j == se) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) t[k] = lcol[g * RPT + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) t[k] = fma(lcol[g * RPT + k], pj, t[k]);
+                if (g == gr) {   // the pivot row itself is scaled, not eliminated
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k)
+                        if (k == kr) t[k] = pj * lcol[r];
+                }
+            }
+            if (j == nn) {   // xB for the next ratio test and the final vertex
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) xcol[g * RPT + k] = t[k];
+            }
+        }
+        ++iters;
+    }
+    __syncthreads();
+    // ---- outputs: x(N(t)) = xB(t), zeros elsewhere (:131-132); basis; counters
+    double* x = d.x + (size_t)lp * n;
+    for (int q = tid; q < n; q += NT) x[q] = 0.0;
+    __syncthreads();
+    for (int q = tid; q < m; q += NT) {
+        x[basis[q]] = xcol[q];
+        d.basis_out[(size_t)lp * m + q] = basis[q];
+    }
+    if (tid == 0) {
+        d.iters[lp] = iters;
+        d.status[lp] = status;
+    }
+}
+
+template <int NT, int RPT, bool DREG>
+static int batched_reg_launch(lp_context* ctx, const BatchedDev& d) {
+    const int nn = d.n - d.m, W = nn + 1, G = (NT - 64) / W, mp = G * RPT;
+    const size_t dbl = sizeof(Published) / 8 + 2 * (size_t)W + (size_t)(mp + 1) + 2 * (size_t)mp;
+    size_t shm = dbl * 8 + sizeof(int) * (size_t)(nn + d.m + d.n);
+    shm = (shm + 15) & ~(size_t)15;
+    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG>), d.batch, NT, shm, ctx->stream, d);
+    return LP_OPTIMAL;
+}
+
 size_t lp_batched_lds_bytes(int m, int n, int* pitch_out) {
     const int nn = n - m, W = nn + 1;
     const int pitch = (W & 1) ? W : W + 1;  // odd pitch: conflict-free column reads
@@ -364,6 +689,17 @@ size_t lp_batched_lds_bytes(int m, int n, int* pitch_out) {
 }
 
 int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
+    if (!d.stamps && !getenv("LP_BATCHED_LDS")) {   // (LP_BATCHED_LDS: A/B against the LDS form)
+        // Register-resident form, smallest row array that holds the shape.  Shapes with many rows per
+        // thread take the 512-thread form first: two workgroups (two LPs) then share a CU and one LP's
+        // one-wave scans run under the other's update (128 x 256: 3.24 ms against 3.63 ms for the
+        // 1024-thread form and 4.02 ms for the LDS form; LP_BATCHED_1024 forces the 1024-thread form).
+        const int rpt = batched_reg_rpt<1024>(d.m, d.n), rpt2 = batched_reg_rpt<512>(d.m, d.n);
+        if (rpt >= 1 && rpt <= 4) return batched_reg_launch<1024, 4, true>(ctx, d);
+        if (rpt >= 1 && rpt <= 12) return batched_reg_launch<1024, 12, true>(ctx, d);
+        if (rpt2 >= 1 && rpt2 <= 44 && !getenv("LP_BATCHED_1024")) return batched_reg_launch<512, 44, false>(ctx, d);
+        if (rpt >= 1 && rpt <= 20) return batched_reg_launch<1024, 20, true>(ctx, d);
+    }
     const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);
     if (d.stamps) {
         LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex<true>),
