@@ -82,6 +82,11 @@ int lp_context_create(int device, void* stream, lp_context** ctx_out) {
 void lp_context_destroy(lp_context* ctx) {
     if (!ctx) return;
     for (auto& b : ctx->pool) (void)hipFree(b.first);
+    for (auto& hb : ctx->bundles) {
+        (void)hipHostFree(hb.pinned);
+        for (hipEvent_t e : hb.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     (void)hipFree(ctx->dcomb6);
     (void)hipFree(ctx->dcomb5);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -117,25 +122,66 @@ static int check_canonical(lp_context* ctx, const double* A, int m, int n, const
 
 void lp_simplex_free(lp_simplex_problem* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
-    SimplexDev& d = p->dev;
-    (void)hipFree(d.T); (void)hipFree(d.lcol); (void)hipFree(d.prow); (void)hipFree(d.basis);
-    (void)hipFree(d.nonbasic); (void)hipFree(d.rowused); (void)hipFree(d.rowpos);
-    (void)hipFree(d.trace_enter); (void)hipFree(d.trace_leave); (void)hipFree(d.state);
-    (void)hipFree(p->dT0); (void)hipFree(p->dscratchT); (void)hipFree(p->dbasis0);
-    (void)hipFree(p->dnonbasic0); (void)hipFree(p->dx);
-    (void)hipFree(p->look.etaL); (void)hipFree(p->look.etaP); (void)hipFree(p->look.dvec);
-    (void)hipFree(p->look.rhs); (void)hipFree(p->look.piv); (void)hipFree(p->look.count);
+    lp_context* ctx = p->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);   // the arena goes back to the pool: nothing may still use it
+    lp_pool_release(ctx, p->arena, p->arena_bytes);
+    (void)hipFree(p->dscratchT);
     (void)hipFree(p->look.stamps);
-    (void)hipFree(p->res.comm); (void)hipFree(p->res.stamps);
-    if (p->h_state) (void)hipHostFree(p->h_state);
-    if (p->ev0) (void)hipEventDestroy(p->ev0);
-    if (p->ev1) (void)hipEventDestroy(p->ev1);
-    if (p->res_ev0) (void)hipEventDestroy(p->res_ev0);
-    if (p->res_ev1) (void)hipEventDestroy(p->res_ev1);
+    (void)hipFree(p->res.stamps);
+    if (p->h_state) {   // pinned block + events: kept for the next problem of this context
+        lp_context::HostBundle hb;
+        hb.pinned = p->h_state;
+        hb.ev[0] = p->ev0; hb.ev[1] = p->ev1; hb.ev[2] = p->res_ev0; hb.ev[3] = p->res_ev1;
+        if (ctx->bundles.size() < 8) {
+            ctx->bundles.push_back(hb);
+        } else {
+            (void)hipHostFree(hb.pinned);
+            for (hipEvent_t e : hb.ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    }
     for (hipEvent_t e : p->upd_events) (void)hipEventDestroy(e);
     delete p;
 }
+
+namespace {
+// T (rows x ld, row-major) <- [A | b] with the cost row c underneath, from the column-major A the
+// caller holds (Eigen's layout): a tiled transpose on the device instead of a strided host loop.
+__global__ __launch_bounds__(256) void k_build_tableau(const double* __restrict__ Acol, const double* __restrict__ b,
+                                                       const double* __restrict__ c, double* __restrict__ T,
+                                                       int m, int n, int ld) {
+    __shared__ double tile[32][33];
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int q = ty; q < 32; q += 8) {   // read: consecutive threads along i (contiguous in column-major A)
+        const int j = j0 + q, i = i0 + tx;
+        tile[q][tx] = (j < n && i < m) ? Acol[(size_t)j * m + i] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {   // write: consecutive threads along j (contiguous in row-major T)
+        const int i = i0 + q, j = j0 + tx;
+        if (i < m && j < n) T[(size_t)i * ld + j] = tile[tx][q];
+    }
+    if (blockIdx.x == 0) {   // column n (b), padding, and (first row of blocks) the cost row
+        for (int q = threadIdx.x; q < 32; q += 256) {
+            const int i = i0 + q;
+            if (i < m) {
+                T[(size_t)i * ld + n] = b[i];
+                for (int j = n + 1; j < ld; ++j) T[(size_t)i * ld + j] = 0.0;
+            }
+        }
+    }
+    if (blockIdx.y == 0) {
+        for (int q = threadIdx.x; q < 32; q += 256) {
+            const int j = j0 + q;
+            if (j < n) T[(size_t)m * ld + j] = c[j];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int j = n; j < ld; ++j) T[(size_t)m * ld + j] = 0.0;
+    }
+}
+}  // namespace
 
 int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
                       const double* c, const int* basis_in, int maximize, int n_orig,
@@ -166,56 +212,89 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
             return -(int)_e;                \
         }                                   \
     } while (0)
-    LP_TRY(hipMalloc(&d.T, p->tableau_bytes));
-    LP_TRY(hipMalloc(&p->dT0, p->tableau_bytes));
-    LP_TRY(hipMalloc(&p->dscratchT, p->tableau_bytes));
-    LP_TRY(hipMalloc(&d.lcol, sizeof(double) * rows));
-    LP_TRY(hipMalloc(&d.prow, sizeof(double) * (size_t)d.ld));
-    LP_TRY(hipMalloc(&d.basis, sizeof(int) * (size_t)m));
-    LP_TRY(hipMalloc(&p->dbasis0, sizeof(int) * (size_t)m));
-    LP_TRY(hipMalloc(&d.nonbasic, (size_t)n));
-    LP_TRY(hipMalloc(&p->dnonbasic0, (size_t)n));
-    LP_TRY(hipMalloc(&d.rowused, (size_t)m));
-    LP_TRY(hipMalloc(&d.rowpos, sizeof(int) * (size_t)m));
-    LP_TRY(hipMalloc(&d.trace_enter, sizeof(int) * (size_t)d.trace_cap));
-    LP_TRY(hipMalloc(&d.trace_leave, sizeof(int) * (size_t)d.trace_cap));
-    LP_TRY(hipMalloc(&d.state, sizeof(SimplexState)));
-    LP_TRY(hipMalloc(&p->dx, sizeof(double) * (size_t)n));
-    LP_TRY(hipHostMalloc(&p->h_state, sizeof(SimplexState)));
-    LP_TRY(hipEventCreate(&p->ev0));
-    LP_TRY(hipEventCreate(&p->ev1));
+    // ---- one arena for everything on the device (taken from / returned to the context's pool:
+    // a repeated one-shot solve of the same shape allocates nothing)
+    LookDev& la = p->look;
+    la.J = lp_lookahead_pick_j(m, n);
+    la.rows_pad = ((m + 1 + 7) / 8) * 8;
+    const size_t J = (size_t)(la.J > 0 ? la.J : 1);
+    const bool resident = lp_resident_plan(m, n, &p->res) != 0;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t staging_bytes = std::max(p->tableau_bytes, sizeof(double) * ((size_t)m * n + m + n) + 256);
+    const size_t oT = take(p->tableau_bytes), oT0 = take(staging_bytes);
+    const size_t olcol = take(sizeof(double) * rows), oprow = take(sizeof(double) * (size_t)d.ld);
+    const size_t obasis = take(sizeof(int) * (size_t)m), obasis0 = take(sizeof(int) * (size_t)m);
+    const size_t onb = take((size_t)n), onb0 = take((size_t)n), oused = take((size_t)m);
+    const size_t orowpos = take(sizeof(int) * (size_t)m);
+    const size_t otre = take(sizeof(int) * (size_t)d.trace_cap), otrl = take(sizeof(int) * (size_t)d.trace_cap);
+    const size_t ostate = take(sizeof(SimplexState)), odx = take(sizeof(double) * (size_t)n);
+    const size_t oetaL = take(sizeof(double) * J * (size_t)la.rows_pad), oetaP = take(sizeof(double) * J * (size_t)d.ld);
+    const size_t odvec = take(sizeof(double) * (size_t)d.ld), orhs = take(sizeof(double) * (size_t)la.rows_pad);
+    const size_t opiv = take(sizeof(int) * 2 * J), ocount = take(sizeof(int));
+    const size_t ocomm = resident ? take(p->res.comm_bytes) : 0;
     {
-        LookDev& la = p->look;
-        la.J = lp_lookahead_pick_j(m, n);
-        la.rows_pad = ((m + 1 + 7) / 8) * 8;
-        const size_t J = (size_t)(la.J > 0 ? la.J : 1);
-        LP_TRY(hipMalloc(&la.etaL, sizeof(double) * J * (size_t)la.rows_pad));
-        LP_TRY(hipMalloc(&la.etaP, sizeof(double) * J * (size_t)d.ld));
-        LP_TRY(hipMalloc(&la.dvec, sizeof(double) * (size_t)d.ld));
-        LP_TRY(hipMalloc(&la.rhs, sizeof(double) * (size_t)la.rows_pad));
-        LP_TRY(hipMalloc(&la.piv, sizeof(int) * 2 * J));
-        LP_TRY(hipMalloc(&la.count, sizeof(int)));
-        LP_TRY(hipMemsetAsync(la.count, 0, sizeof(int), ctx->stream));
+        size_t got = 0;
+        LP_TRY(lp_pool_alloc(ctx, &p->arena, off, &got));
+        p->arena_bytes = got;
     }
+    char* base = static_cast<char*>(p->arena);
+    d.T = reinterpret_cast<double*>(base + oT);
+    p->dT0 = reinterpret_cast<double*>(base + oT0);
+    d.lcol = reinterpret_cast<double*>(base + olcol);
+    d.prow = reinterpret_cast<double*>(base + oprow);
+    d.basis = reinterpret_cast<int*>(base + obasis);
+    p->dbasis0 = reinterpret_cast<int*>(base + obasis0);
+    d.nonbasic = reinterpret_cast<unsigned char*>(base + onb);
+    p->dnonbasic0 = reinterpret_cast<unsigned char*>(base + onb0);
+    d.rowused = reinterpret_cast<unsigned char*>(base + oused);
+    d.rowpos = reinterpret_cast<int*>(base + orowpos);
+    d.trace_enter = reinterpret_cast<int*>(base + otre);
+    d.trace_leave = reinterpret_cast<int*>(base + otrl);
+    d.state = reinterpret_cast<SimplexState*>(base + ostate);
+    p->dx = reinterpret_cast<double*>(base + odx);
+    la.etaL = reinterpret_cast<double*>(base + oetaL);
+    la.etaP = reinterpret_cast<double*>(base + oetaP);
+    la.dvec = reinterpret_cast<double*>(base + odvec);
+    la.rhs = reinterpret_cast<double*>(base + orhs);
+    la.piv = reinterpret_cast<int*>(base + opiv);
+    la.count = reinterpret_cast<int*>(base + ocount);
+    if (resident) p->res.comm = base + ocomm;
+    if (!ctx->bundles.empty()) {
+        const lp_context::HostBundle hb = ctx->bundles.back();
+        ctx->bundles.pop_back();
+        p->h_state = static_cast<SimplexState*>(hb.pinned);
+        p->ev0 = hb.ev[0]; p->ev1 = hb.ev[1]; p->res_ev0 = hb.ev[2]; p->res_ev1 = hb.ev[3];
+    } else {
+        LP_TRY(hipHostMalloc(&p->h_state, sizeof(SimplexState) + 64));
+        LP_TRY(hipEventCreate(&p->ev0));
+        LP_TRY(hipEventCreate(&p->ev1));
+    }
+    hipStream_t s = ctx->stream;
+    LP_TRY(hipMemsetAsync(la.count, 0, sizeof(int), s));
 
-    if (lp_resident_plan(m, n, &p->res)) LP_TRY(hipMalloc(&p->res.comm, p->res.comm_bytes));
-
-    // Initial tableau [A | b] with the cost row c underneath, row-major (host-side O(mn)
-    // layout change: Eigen's column-major A -> rows that the update kernel streams).
-    std::vector<double> T(rows * (size_t)d.ld, 0.0);
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < m; ++i) T[(size_t)i * d.ld + j] = A[(size_t)j * m + i];
-    for (int i = 0; i < m; ++i) T[(size_t)i * d.ld + n] = b[i];
-    for (int j = 0; j < n; ++j) T[(size_t)m * d.ld + j] = c[j];
+    // ---- initial tableau [A | b] with the cost row c underneath, row-major: A goes up as the caller
+    // holds it (column-major) into the staging area and is transposed on the device
+    double* dA = p->dT0;
+    double* db = dA + (size_t)m * n;
+    double* dc = db + m;
     std::vector<unsigned char> nonbasic((size_t)n, 1);
     for (int t = 0; t < m; ++t) nonbasic[(size_t)basis_in[t]] = 0;
-    hipStream_t s = ctx->stream;
-    LP_TRY(hipMemcpyAsync(d.T, T.data(), p->tableau_bytes, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(dA, A, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(db, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, s));
+    LP_TRY(hipMemcpyAsync(dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_build_tableau, dim3(lp_ceil_div(n, 32), lp_ceil_div(m, 32)), 256, 0, s, dA, db, dc, d.T, m, n,
+                       d.ld);
     LP_TRY(hipMemcpyAsync(d.basis, basis_in, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->dbasis0, basis_in, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(d.nonbasic, nonbasic.data(), (size_t)n, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->dnonbasic0, nonbasic.data(), (size_t)n, hipMemcpyHostToDevice, s));
     LP_TRY(hipStreamSynchronize(s));
+    LP_TRY(hipGetLastError());
 #undef LP_TRY
 
     // computeBFS (SimplexSolover.h:423): nothing to do for the slack identity basis with

@@ -24,6 +24,13 @@ struct lp_context {
     // shape-independent subset tables of the enumeration's leaf kernels, built once per context
     unsigned* dcomb6 = nullptr;
     unsigned* dcomb5 = nullptr;
+    // pinned state blocks and event sets of freed simplex problems (hipHostMalloc / hipEventCreate
+    // cost more than a small solve)
+    struct HostBundle {
+        void* pinned = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    };
+    std::vector<HostBundle> bundles;
 };
 
 // Best-fit buffer of at least `bytes` from the context's pool (not more than twice as large), else

@@ -571,6 +571,7 @@ int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, 
     // Stage a valid pivot (eta column + pivot-row copy) with the crash selector's
     // arithmetic, then replay the update kernel.  Values drift (the same eta is
     // re-applied), which is irrelevant for timing; the tableau is restored afterwards.
+    if (!p->dscratchT) LP_HIP(ctx, hipMalloc(&p->dscratchT, p->tableau_bytes));   // (micro-benchmarks only)
     LP_HIP(ctx, hipMemcpyAsync(p->dscratchT, d.T, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
     std::vector<double> lcol((size_t)d.m + 1), prow((size_t)d.ld);
     std::vector<double> Th((size_t)(d.m + 1) * d.ld);

@@ -479,6 +479,7 @@ int lp_lookahead_bench_update(lp_simplex_problem* p, int iters, float* ms_per_la
     if (rc) return rc;
     const size_t shm = sel_lds_bytes(d.m, d.n, la.J);
     const dim3 ugrid(lp_ceil_div(d.ld / 2, LU_TX), lp_ceil_div(d.m + 1, LU_ROWS));
+    if (!p->dscratchT) LP_HIP(ctx, hipMalloc(&p->dscratchT, p->tableau_bytes));   // (micro-benchmarks only)
     LP_HIP(ctx, hipMemcpyAsync(p->dscratchT, d.T, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_look_state_init, 1, 1, 0, s, d, 1e-9, 1 << 30);
     lp_lookahead_init_vectors(p);

@@ -65,8 +65,11 @@ struct lp_simplex_problem {
     ResidentDev res{};            // res.G == 0: shape outside the chip-resident path
     int n_orig = 0;
     size_t tableau_bytes = 0;
-    double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset
-    double* dscratchT = nullptr;  // scratch copy used by the update micro-benchmark
+    void* arena = nullptr;        // ONE device allocation (from the context's pool) behind every pointer below
+    size_t arena_bytes = 0;
+    double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset; also the
+                                  // staging area of the upload (column-major A) and of the crash's row permutation
+    double* dscratchT = nullptr;  // scratch copy used by the update micro-benchmarks (allocated on first use)
     int* dbasis0 = nullptr;
     unsigned char* dnonbasic0 = nullptr;
     double* dx = nullptr;         // n: extracted vertex
