@@ -147,7 +147,10 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
     if (k >= G) return;
     SimplexState* st = d.state;
     if (st->status != kRunning) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (wave-uniform by construction; telling the compiler makes every `wave == ...` a scalar branch
+    // instead of an exec-mask region)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = d.m, n = d.n, ld = d.ld;
     const int mpad = rd.mpad;
     const int W2 = (mpad > 64) ? 1 : 0;   // the wave that finishes the ratio test while wave 0 polls
@@ -473,8 +476,11 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         }
         __syncthreads();
         RS_STAMP(3);
-        int mode = sh.ctl->mode;
-        if (sh.ctl->fail) mode = MODE_FAIL;
+        // the whole decision block in one go (four 16-byte LDS reads in flight together; field by field,
+        // each read's round trip was paid in turn behind its readfirstlane)
+        Ctl cc = *sh.ctl;
+        int mode = cc.mode;
+        if (cc.fail) mode = MODE_FAIL;
         bool from_colS = false;
         if (mode == MODE_SLOW) {
             // ---- exact replay of the scan over all n published reduced costs (near-tie)
@@ -560,7 +566,8 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     }
                 }
                 __syncthreads();
-                mode = sh.ctl->mode;
+                cc = *sh.ctl;
+                mode = cc.mode;
                 from_colS = true;
             }
         }
@@ -568,11 +575,11 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             status = mode == MODE_OPTIMAL ? LP_OPTIMAL : mode == MODE_UNBOUNDED ? LP_UNBOUNDED : kResidentFailed;
             break;
         }
-        const int kst = __builtin_amdgcn_readfirstlane(sh.ctl->kst);
-        const int e = __builtin_amdgcn_readfirstlane(sh.ctl->e);
-        const int r = __builtin_amdgcn_readfirstlane(sh.ctl->r);
-        const int oldb = __builtin_amdgcn_readfirstlane(sh.ctl->oldb);
-        const double ur = sh.ctl->ur;
+        const int kst = __builtin_amdgcn_readfirstlane(cc.kst);
+        const int e = __builtin_amdgcn_readfirstlane(cc.e);
+        const int r = __builtin_amdgcn_readfirstlane(cc.r);
+        const int oldb = __builtin_amdgcn_readfirstlane(cc.oldb);
+        const double ur = cc.ur;
         // ---- my part of the pivot row (before scaling), broadcast through LDS
         if (tid == r) {
 #pragma unroll
@@ -591,8 +598,8 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         v4i gcol = {0, 0, 0, 0};
         if (want_col) gcol = ld16(cm.r, coff);
         const unsigned ep_col = ep;
-        const double inv = sh.ctl->inv;   // F(r,r) = 1/u_r, :204
-        const double lm = sh.ctl->lm;     // F row of the reduced costs: -T[m][e]/u_r
+        const double inv = cc.inv;   // F(r,r) = 1/u_r, :204
+        const double lm = cc.lm;     // F row of the reduced costs: -T[m][e]/u_r
         RS_STAMP(4);
         __syncthreads();
         RS_STAMP(5);

@@ -198,6 +198,53 @@ def test_config1_against_reference_shaped_golden(ctx):
         assert (np.abs(g["x"][nz] - xref[nz]) <= 1e-10 * np.abs(xref[nz]) + 1e-14 * scale).all()
 
 
+def test_resident_solves_under_contention(ctx):
+    """The chip-resident kernel's workgroups wait for each other inside one launch, so they must all
+    become resident and every hand-off must survive an uneven, busy chip: four host threads, each
+    with a context (stream) of its own, solve different LPs at the same time on the one device —
+    their launches compete for the same XCD's CUs and L2 — while the main thread runs enumeration
+    passes underneath.  Every solve must be the chip-resident one (no silent fallback: the launch
+    count says so) and bit-exact."""
+    import threading
+    cases = [(31, 256, 512), (32, 200, 700), (33, 512, 1024), (34, 96, 2000)]
+    refs, outs = {}, {}
+    for seed, m, n in cases:
+        A, b, c, basis = lpcases.random_lp(seed, m, n)
+        refs[seed] = (A, b, c, basis, o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14))
+
+    def run(seed, m, n):
+        cx = capi.Context(0)
+        A, b, c, basis, _ = refs[seed]
+        res = []
+        for _ in range(6):
+            p = cx.simplex_problem(A, b, c, basis, True, n - m)
+            rc, st = p.run(algo=capi.SIMPLEX_RESIDENT)
+            d = p.download(trace_cap=max(st.pivots, 1))
+            p.free()
+            res.append((rc, st.pivots, st.launches, d))
+        cx.close()
+        outs[seed] = res
+
+    th = [threading.Thread(target=run, args=cs) for cs in cases]
+    for t in th:
+        t.start()
+    Ae, be, ce, _ = lpcases.random_lp(0, 14, 28)
+    ep = ctx.enum_problem(Ae, be, ce, True)
+    for _ in range(20):
+        ep.range(0, ep.total)
+    ep.free()
+    for t in th:
+        t.join()
+    for seed, m, n in cases:
+        r = refs[seed][4]
+        for rc, pivots, launches, d in outs[seed]:
+            assert rc == r["status"] == 0 and pivots == r["iters"]
+            assert launches == 2, "the solve fell back to the launch-based path"
+            assert np.array_equal(d["basis"], r["basis"]) and np.array_equal(d["x"], r["x"]) and d["obj"] == r["obj"]
+            k = r["iters"]
+            assert list(zip(d["trace_enter"][:k].tolist(), d["trace_leave"][:k].tolist())) == r["trace"][:k]
+
+
 def test_update_microbenchmarks_and_profiling(ctx):
     """The measurement hooks bench.py uses leave the problem intact."""
     A, b, c, basis = lpcases.random_lp(3, 64, 160)
