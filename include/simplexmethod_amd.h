@@ -260,8 +260,9 @@ int lp_comm_create_local(int world, lp_comm** comms_out /* world entries */);
 int lp_comm_rank(const lp_comm* c);
 int lp_comm_world(const lp_comm* c);
 void lp_comm_destroy(lp_comm* c);
-/* comm == NULL: a single participant (no exchange).  Outputs as lp_enum_solve; counts_out[3] are
- * the node-wide totals.  Every participant must call it (a failing one still takes part in the
+/* comm == NULL: a single participant (no exchange).  Outputs as lp_enum_solve (x_out and basis_out
+ * may both be NULL: the winning rank, objective and counts then come straight from the exchange and
+ * no vertex is evaluated); counts_out[3] are the node-wide totals.  Every participant must call it (a failing one still takes part in the
  * exchange, and every participant returns its status).                                          */
 int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double* x_out, int* basis_out,
                           uint64_t* rank_out, double* obj_out, uint64_t* counts_out);

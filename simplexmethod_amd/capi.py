@@ -422,18 +422,19 @@ class EnumProblem:
                                                          C.byref(r)))
         return int(r.value)
 
-    def solve_sharded(self, comm=None, n_orig=None):
+    def solve_sharded(self, comm=None, n_orig=None, want_vertex=True):
         """lp_enum_solve_sharded: this participant's shard of the rank space + the one exchange.
-        comm: a Comm (or None = single participant).  Blocks until every participant has called."""
+        comm: a Comm (or None = single participant).  Blocks until every participant has called.
+        want_vertex=False: rank, objective and counts only (no vertex kernel)."""
         n_orig = self.n if n_orig is None else n_orig
         x = np.zeros(n_orig)
         bo = np.zeros(self.m, dtype=np.int32)
         rank = C.c_uint64(0)
         obj = C.c_double(float("nan"))
         counts = (C.c_uint64 * 3)()
-        rc = self.ctx.check(self.ctx.lib.lp_enum_solve_sharded(comm.h if comm is not None else None, self.h,
-                                                               n_orig, _d(x), _i(bo), C.byref(rank),
-                                                               C.byref(obj), counts))
+        rc = self.ctx.check(self.ctx.lib.lp_enum_solve_sharded(
+            comm.h if comm is not None else None, self.h, n_orig, _d(x) if want_vertex else None,
+            _i(bo) if want_vertex else None, C.byref(rank), C.byref(obj), counts))
         return dict(status=rc, x=x, basis=bo, rank=int(rank.value), obj=obj.value,
                     counts=[int(v) for v in counts])
 

@@ -89,6 +89,10 @@ void lp_context_destroy(lp_context* ctx) {
     }
     (void)hipFree(ctx->dcomb6);
     (void)hipFree(ctx->dcomb5);
+    for (hipStream_t a : ctx->aux_stream)
+        if (a) (void)hipStreamDestroy(a);
+    for (hipEvent_t e : ctx->aux_event)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

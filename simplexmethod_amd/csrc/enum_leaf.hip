@@ -843,13 +843,40 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
     if (fused) {
-        const int lanes = bound < 300000 ? kItemLanesNarrow : kItemLanesWide;
-        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, ctx->stream, p->dev, pd,
-                           roots, level, bound, THIN_TAIL, lanes, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        // The three leaf kernels are independent of each other (own item table / work cursor, results
+        // through atomics), and the thin kernel does not even need the item tables: they run on three
+        // streams, so that the thin kernel overlaps the item builder and every kernel's tail (persistent
+        // waves running out of items) is filled by the next kernel's blocks.  The library's stream
+        // waits for the other two before anything that follows (list evaluation, result copy).
+        if (!ctx->aux_stream[0]) {
+            for (hipStream_t& a : ctx->aux_stream) LP_HIP(ctx, hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+            for (hipEvent_t& ev : ctx->aux_event) LP_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        hipStream_t s = ctx->stream, sT = ctx->aux_stream[0], s1 = ctx->aux_stream[1];
+        const bool side = getenv("LP_ENUM_ONE_STREAM") == nullptr;   // (A/B: everything on the library's stream)
+        if (!side) sT = s1 = s;
+        int lanes = bound < 300000 ? kItemLanesNarrow : kItemLanesWide;
+        if (const char* ev = getenv("LP_ENUM_ITEM_LANES")) lanes = atoi(ev) == 4 ? 4 : 8;   // (A/B)
+        if (side) {
+            LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
+            LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
+        }
         hipLaunchKernelGGL(k_enum_thin, (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12),
-                           LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
+                           LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+        hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, s, p->dev, pd,
+                           roots, level, bound, THIN_TAIL, lanes, b, e);
+        if (side) {
+            LP_HIP(ctx, hipEventRecord(ctx->aux_event[1], s));          // both item tables are built
+            LP_HIP(ctx, hipStreamWaitEvent(s1, ctx->aux_event[1], 0));
+        }
+        hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+        hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+        if (side) {
+            LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));
+            LP_HIP(ctx, hipEventRecord(ctx->aux_event[2], s1));
+            LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[0], 0));
+            LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[2], 0));
+        }
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 1024), 1024, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, 1, b, e);

@@ -105,6 +105,9 @@ struct lp_enum_problem {
     std::vector<PrefixChunk> pchunks;
     bool pchunks_valid = false;
     uint64_t pchunks_begin = 0, pchunks_end = 0;
+    // shard of the last lp_enum_solve_sharded call (enum_sharded.hip)
+    int shard_rank = -1, shard_world = -1;
+    uint64_t shard_lo = 0, shard_hi = 0;
     // tie rule already applied on the device against the range's own best score (prefix path)
     bool spec_valid = false;
     double spec_star = 0.0, spec_tol = 0.0;

@@ -214,8 +214,22 @@ int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double*
     const EnumDev& d = p->dev;
     constexpr double kTol = 1e-9;   // Solver::EPS, /root/reference/src/SimplexSolover.h:13
     constexpr long long kNone = 0x7FFFFFFFFFFFFFFFLL;
+    // this participant's shard: the cost-balanced cut is host combinatorics (a binary search over
+    // prefix ranks), computed once per (rank, world) and kept with the problem
     uint64_t lo = 0, hi = 0;
-    int status = lp_enum_shard_bounds(d.n, d.m, rank, world, &lo, &hi);
+    int status = LP_OPTIMAL;
+    if (p->shard_rank == rank && p->shard_world == world) {
+        lo = p->shard_lo;
+        hi = p->shard_hi;
+    } else {
+        status = lp_enum_shard_bounds(d.n, d.m, rank, world, &lo, &hi);
+        if (status == LP_OPTIMAL) {
+            p->shard_rank = rank;
+            p->shard_world = world;
+            p->shard_lo = lo;
+            p->shard_hi = hi;
+        }
+    }
     // ---- my shard: pass 1, and the tie rule against my own best (no collective so far)
     double z = 0.0, score = -INFINITY;
     uint64_t counts[3] = {0, 0, 0}, first = UINT64_MAX;
@@ -286,6 +300,10 @@ int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double*
         return LP_INFEASIBLE;
     }
     if (rank_out) *rank_out = (uint64_t)grank;
+    if (!x_out && !basis_out) {   // the optimum itself travelled with the records: no vertex kernel needed
+        if (obj_out) *obj_out = zstar;
+        return LP_OPTIMAL;
+    }
     // the problem is replicated: every participant evaluates the winning vertex itself
     int verdict = 0;
     return lp_enum_vertex(p, (uint64_t)grank, n_orig, x_out, basis_out, obj_out, &verdict);

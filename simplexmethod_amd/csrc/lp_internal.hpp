@@ -24,6 +24,10 @@ struct lp_context {
     // shape-independent subset tables of the enumeration's leaf kernels, built once per context
     unsigned* dcomb6 = nullptr;
     unsigned* dcomb5 = nullptr;
+    // two more streams + events (created on first use): the enumeration's independent leaf kernels run
+    // side by side so that one kernel's tail is filled by the next one's head
+    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    hipEvent_t aux_event[3] = {nullptr, nullptr, nullptr};
     // pinned state blocks and event sets of freed simplex problems (hipHostMalloc / hipEventCreate
     // cost more than a small solve)
     struct HostBundle {
