@@ -79,8 +79,12 @@ int lp_context_create(int device, void* stream, lp_context** ctx_out) {
     return LP_OPTIMAL;
 }
 
+static void enum_destroy(lp_enum_problem* p);   // (below: releases a kept enumeration shell)
+
 void lp_context_destroy(lp_context* ctx) {
     if (!ctx) return;
+    for (void* q : ctx->enum_shells) enum_destroy(static_cast<lp_enum_problem*>(q));
+    ctx->enum_shells.clear();
     for (auto& b : ctx->pool) (void)hipFree(b.first);
     for (auto& hb : ctx->bundles) {
         (void)hipHostFree(hb.pinned);
@@ -627,7 +631,7 @@ int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_ou
     return LP_OPTIMAL;
 }
 
-void lp_enum_free(lp_enum_problem* p) {
+static void enum_destroy(lp_enum_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dbinom);
@@ -653,6 +657,20 @@ void lp_enum_free(lp_enum_problem* p) {
     delete p;
 }
 
+// A freed problem keeps its allocations (all sized for the largest shape) in the context for the next
+// lp_enum_upload; beyond two kept shells it is really released.
+void lp_enum_free(lp_enum_problem* p) {
+    if (!p) return;
+    lp_context* ctx = p->ctx;
+    if (p->complete && ctx->enum_shells.size() < 2) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->enum_shells.push_back(p);
+        return;
+    }
+    enum_destroy(p);
+}
+
 int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
                    const double* c, int maximize, lp_enum_problem** problem_out) {
     if (!ctx || !problem_out) return LP_BAD_ARG;
@@ -663,8 +681,31 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_FAIL(ctx, LP_BAD_ARG, "enumeration supports n <= 64 and m <= 32 (ranks must fit 64 bits)");
     if (lp_host_binom(n, m) == 0) LP_FAIL(ctx, LP_BAD_ARG, "C(n,m) overflows 64 bits");
     LP_HIP(ctx, hipSetDevice(ctx->device));
-    lp_enum_problem* p = new lp_enum_problem();
-    p->ctx = ctx;
+    unsigned long long want_cap = 1ULL << 22;
+    if (const char* e = getenv("LP_ENUM_LIST_CAP")) {   // tests: force the sub-range path on small problems
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 64 && v < want_cap) want_cap = v;
+    }
+    lp_enum_problem* p = nullptr;
+    while (!p && !ctx->enum_shells.empty()) {   // a kept shell: every allocation is already there
+        lp_enum_problem* q = static_cast<lp_enum_problem*>(ctx->enum_shells.back());
+        ctx->enum_shells.pop_back();
+        if (q->prefix.list_cap == want_cap) p = q; else enum_destroy(q);
+    }
+    const bool fresh = p == nullptr;
+    if (fresh) {
+        p = new lp_enum_problem();
+        p->ctx = ctx;
+    } else {   // forget what the previous problem left behind
+        p->list_valid = p->spec_valid = p->pchunks_valid = false;
+        p->pchunks.clear();
+        p->shard_rank = p->shard_world = -1;
+        p->last_begin = p->last_end = p->last_per_chunk = 0;
+        p->last_chunks = 0;
+        p->last_algo = 0;
+        p->list_n = 0;
+    }
+    p->complete = false;
     EnumDev& d = p->dev;
     d.m = m;
     d.n = n;
@@ -687,29 +728,27 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         }                                   \
     } while (0)
     hipStream_t s = ctx->stream;
-    LP_TRY(hipMalloc(&p->dA, sizeof(double) * Arow.size()));
-    LP_TRY(hipMalloc(&p->db, sizeof(double) * (size_t)m));
-    LP_TRY(hipMalloc(&p->dc, sizeof(double) * (size_t)n));
-    LP_TRY(hipMalloc(&p->dbinom, sizeof(unsigned long long) * binom.size()));
-    LP_TRY(hipMalloc(&d.result, sizeof(EnumResult)));
-    LP_TRY(hipMalloc(&d.chunk_best, sizeof(double) * (size_t)(p->chunk_cap + 64)));
-    LP_TRY(hipMalloc(&p->dvx, sizeof(double) * (kEnumMaxM + 1)));
-    LP_TRY(hipMalloc(&p->dvi, sizeof(int) * (kEnumMaxM + 1)));
-    LP_TRY(hipHostMalloc(&p->h_result, sizeof(EnumResult)));
-    LP_TRY(hipEventCreate(&p->ev0));
-    LP_TRY(hipEventCreate(&p->ev1));
+    if (fresh) {   // sized for the largest shape (m <= 32, n <= 64): a shell serves any later problem
+        LP_TRY(hipMalloc(&p->dA, sizeof(double) * (size_t)kEnumMaxM * (kEnumMaxN + 1)));
+        LP_TRY(hipMalloc(&p->db, sizeof(double) * (size_t)kEnumMaxM));
+        LP_TRY(hipMalloc(&p->dc, sizeof(double) * (size_t)kEnumMaxN));
+        LP_TRY(hipMalloc(&p->dbinom, sizeof(unsigned long long) * binom.size()));
+        LP_TRY(hipMalloc(&d.result, sizeof(EnumResult)));
+        LP_TRY(hipMalloc(&d.chunk_best, sizeof(double) * (size_t)(p->chunk_cap + 64)));
+        LP_TRY(hipMalloc(&p->dvx, sizeof(double) * (kEnumMaxM + 1)));
+        LP_TRY(hipMalloc(&p->dvi, sizeof(int) * (kEnumMaxM + 1)));
+        LP_TRY(hipHostMalloc(&p->h_result, sizeof(EnumResult)));
+        LP_TRY(hipEventCreate(&p->ev0));
+        LP_TRY(hipEventCreate(&p->ev1));
+        LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
+                              hipMemcpyHostToDevice, s));
+    }
     LP_TRY(hipMemcpyAsync(p->dA, Arow.data(), sizeof(double) * Arow.size(), hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->db, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, s));
     LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
-    LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
-                          hipMemcpyHostToDevice, s));
-    {   // shared-prefix path: small control words, the feasible list
+    if (fresh) {   // shared-prefix path: small control words, the feasible list
         PrefixDev& pd = p->prefix;
-        pd.list_cap = 1ULL << 22;
-        if (const char* e = getenv("LP_ENUM_LIST_CAP")) {   // tests: force the sub-range path on small problems
-            const unsigned long long v = strtoull(e, nullptr, 10);
-            if (v >= 64 && v < pd.list_cap) pd.list_cap = v;
-        }
+        pd.list_cap = want_cap;
         LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
         LP_TRY(hipMalloc(&pd.item_count, 2 * sizeof(int)));
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
@@ -772,6 +811,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     d.b = p->db;
     d.c = p->dc;
     d.binom = p->dbinom;
+    p->complete = true;
     *problem_out = p;
     return LP_OPTIMAL;
 }

@@ -67,6 +67,7 @@ struct PrefixDev {
 
 struct lp_enum_problem {
     lp_context* ctx = nullptr;
+    bool complete = false;           // every allocation of lp_enum_upload succeeded (a shell worth keeping)
     EnumDev dev{};
     double* dA = nullptr;
     double* db = nullptr;

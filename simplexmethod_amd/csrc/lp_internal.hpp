@@ -28,6 +28,9 @@ struct lp_context {
     // side by side so that one kernel's tail is filled by the next one's head
     hipStream_t aux_stream[2] = {nullptr, nullptr};
     hipEvent_t aux_event[3] = {nullptr, nullptr, nullptr};
+    // freed enumeration problems with every allocation intact (their ~20 device / pinned allocations
+    // and events cost more than a C(28,14) solve); lp_enum_upload refills one instead of allocating
+    std::vector<void*> enum_shells;
     // pinned state blocks and event sets of freed simplex problems (hipHostMalloc / hipEventCreate
     // cost more than a small solve)
     struct HostBundle {
