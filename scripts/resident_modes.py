@@ -1,3 +1,5 @@
+"""The chip-resident simplex under its placement-independent modes: default (one XCD, plain stores),
+write-through stores forced, participants spread over all XCDs, and both."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
