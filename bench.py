@@ -116,6 +116,27 @@ def pivot_leg(ctx, args):
         look = best_of(capi.SIMPLEX_LOOKAHEAD, 3)
     except capi.LPError:
         look = None
+    # per-phase cycle sums of the chip-resident kernel (diagnostic instantiation: ~20 % slower than the
+    # product kernel, so only the SHARES are meaningful; workgroup 0, summed over the solve)
+    phases = None
+    if resident:
+        import ctypes as C
+        ctx.lib.lp_debug_simplex_stamps(p.h, 16, None)          # turns the instrumented instantiation on
+        for _ in range(3):   # (the first launch of the instrumented instantiation pays its code load)
+            p.reset()
+            rc_s, st_s = p.run(algo=args.simplex_algo)
+        buf = (C.c_ulonglong * 16)()
+        ctx.lib.lp_debug_simplex_stamps(p.h, 1, buf)
+        names = ["loop", "poll_records_A", "decide_and_record_B", "decision_barrier",
+                 "read_decision_pivot_row_to_lds_request_column", "pivot_row_barrier",
+                 "reduced_costs_and_next_pricing", "column_wait_eta_entry",
+                 "candidate_publish_ratio_stage1", "ratio_barrier", "ratio_stage2_record_B_prefetch",
+                 "rank1_update_32_columns"]
+        cyc = [buf[i] / max(st_s.pivots, 1) for i in range(12)]
+        tot = sum(cyc)
+        phases = {"instrumented_solve_ms": round(st_s.solve_ms, 3), "cycles_per_pivot_total": round(tot, 1),
+                  "cycles_per_pivot": {k: round(v, 1) for k, v in zip(names, cyc)},
+                  "rank1_update_share_of_pivot": round(cyc[11] / tot, 4) if tot else None}
     p.reset()
     upd1_ms = min(p.bench_update(0, 0, 200) for _ in range(3))   # ms per rank-1 update launch
     try:   # rank-J update alone: 200 back-to-back launches between two events
@@ -141,6 +162,8 @@ def pivot_leg(ctx, args):
         "one_shot_host_buffers_ms": round(1e3 * t_one, 3),
         "budget_us_per_pivot_at_70pct_of_8TBs": round(bytes_per_pivot / (0.7 * HBM_PEAK_GBS * 1e9) * 1e6, 3),
     }
+    if phases is not None:
+        out["resident_kernel_phases_workgroup0"] = phases
     if look is not None:
         out["lookahead_path_solve_ms"] = round(look["solve_ms"], 3)
         out["lookahead_path_us_per_pivot"] = round(1e3 * look["solve_ms"] / max(look["pivots"], 1), 3)
