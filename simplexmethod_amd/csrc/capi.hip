@@ -631,6 +631,33 @@ int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_ou
     return LP_OPTIMAL;
 }
 
+// The feasible list of the shared-prefix path: rank, record index and score of each entry.
+static void enum_list_release(lp_enum_problem* p) {
+    PrefixDev& pd = p->prefix;
+    lp_pool_release(p->ctx, pd.list, sizeof(unsigned long long) * pd.list_cap);
+    lp_pool_release(p->ctx, pd.scores, sizeof(double) * pd.list_cap);
+    lp_pool_release(p->ctx, pd.list_rec, sizeof(int) * pd.list_cap);
+    pd.list = nullptr;
+    pd.scores = nullptr;
+    pd.list_rec = nullptr;
+    pd.list_cap = 0;
+}
+static hipError_t enum_list_alloc(lp_enum_problem* p, unsigned long long cap) {
+    PrefixDev& pd = p->prefix;
+    size_t got = 0;
+    hipError_t e = lp_pool_alloc(p->ctx, (void**)&pd.list, sizeof(unsigned long long) * cap, &got);
+    if (e == hipSuccess) e = lp_pool_alloc(p->ctx, (void**)&pd.scores, sizeof(double) * cap, &got);
+    if (e == hipSuccess) e = lp_pool_alloc(p->ctx, (void**)&pd.list_rec, sizeof(int) * cap, &got);
+    if (e != hipSuccess) {
+        // the sizes lp_pool_release is told must be those of the failed request
+        pd.list_cap = cap;
+        enum_list_release(p);
+        return e;
+    }
+    pd.list_cap = cap;
+    return hipSuccess;
+}
+
 static void enum_destroy(lp_enum_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
@@ -639,8 +666,7 @@ static void enum_destroy(lp_enum_problem* p) {
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor);
-    lp_pool_release(p->ctx, p->prefix.list, sizeof(unsigned long long) * p->prefix.list_cap);
-    lp_pool_release(p->ctx, p->prefix.scores, sizeof(double) * p->prefix.list_cap);
+    enum_list_release(p);
     (void)hipFree(p->prefix.list_count);
     lp_pool_release(p->ctx, p->prefix.items, sizeof(int4) * (size_t)p->prefix.item_cap);
     lp_pool_release(p->ctx, p->prefix.items2, sizeof(int4) * (size_t)p->prefix.item_cap2);
@@ -682,15 +708,23 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     if (lp_host_binom(n, m) == 0) LP_FAIL(ctx, LP_BAD_ARG, "C(n,m) overflows 64 bits");
     LP_HIP(ctx, hipSetDevice(ctx->device));
     unsigned long long want_cap = 1ULL << 22;
+    bool forced_cap = false;
     if (const char* e = getenv("LP_ENUM_LIST_CAP")) {   // tests: force the sub-range path on small problems
         const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 64 && v < want_cap) want_cap = v;
+        forced_cap = true;
+    } else if (const char* e2 = getenv("LP_ENUM_LIST_START")) {   // tests: a small first list that may grow
+        const unsigned long long v = strtoull(e2, nullptr, 10);
         if (v >= 64 && v < want_cap) want_cap = v;
     }
     lp_enum_problem* p = nullptr;
     while (!p && !ctx->enum_shells.empty()) {   // a kept shell: every allocation is already there
         lp_enum_problem* q = static_cast<lp_enum_problem*>(ctx->enum_shells.back());
         ctx->enum_shells.pop_back();
-        if (q->prefix.list_cap == want_cap) p = q; else enum_destroy(q);
+        // (a list that grew for a degenerate problem is kept unless it is far larger than the default)
+        const bool fits = forced_cap ? q->prefix.list_cap == want_cap
+                                     : (q->prefix.list_cap >= want_cap && q->prefix.list_cap <= 64 * want_cap);
+        if (fits) p = q; else enum_destroy(q);
     }
     const bool fresh = p == nullptr;
     if (fresh) {
@@ -748,17 +782,12 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     if (fresh) {   // shared-prefix path: small control words, the feasible list
         PrefixDev& pd = p->prefix;
-        pd.list_cap = want_cap;
         LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
         LP_TRY(hipMalloc(&pd.item_count, 2 * sizeof(int)));
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
         LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
         LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
-        {
-            size_t got = 0;
-            LP_TRY(lp_pool_alloc(ctx, (void**)&pd.list, sizeof(unsigned long long) * pd.list_cap, &got));
-            LP_TRY(lp_pool_alloc(ctx, (void**)&pd.scores, sizeof(double) * pd.list_cap, &got));
-        }
+        LP_TRY(enum_list_alloc(p, want_cap));
         LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
         LP_TRY(hipHostMalloc(&p->h_level_counts, sizeof(int) * 32));
         LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
@@ -820,6 +849,23 @@ static int check_range(lp_enum_problem* p, uint64_t begin, uint64_t end) {
     const uint64_t total = lp_host_binom(p->dev.n, p->dev.m);
     if (begin > end || end > total) LP_FAIL(p->ctx, LP_BAD_ARG, "rank range outside [0, C(n,m)]");
     return LP_OPTIMAL;
+}
+
+// Makes the feasible list hold `nfeas` entries (20 bytes each) if the device has the memory.
+static bool enum_list_grow(lp_enum_problem* p, uint64_t nfeas) {
+    if (getenv("LP_ENUM_LIST_CAP")) return false;   // tests pin the list to exercise the sub-range path
+    const unsigned long long old_cap = p->prefix.list_cap;
+    const unsigned long long want = nfeas + nfeas / 16 + 4096;
+    if (want <= old_cap) return false;
+    (void)hipSetDevice(p->ctx->device);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    if ((size_t)want * 20 + (size_t(2) << 30) > free_b) return false;
+    enum_list_release(p);
+    if (enum_list_alloc(p, want) == hipSuccess) return true;
+    (void)hipGetLastError();
+    if (enum_list_alloc(p, old_cap) != hipSuccess) p->complete = false;   // (cannot happen: it was just released)
+    return false;
 }
 
 // Shared-prefix enumeration of a range whose feasible subsets overflow the list: sub-ranges sized
@@ -913,8 +959,20 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
             if (!lp_enum_prefix_supported(p))
                 LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 16 and 2 <= n-m <= 16");
             rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
+            if (rc == kEnumListOverflow && enum_list_grow(p, *p->h_list_count)) {
+                // more feasible subsets than the list held (a degenerate LP: up to every non-singular
+                // basis is feasible); the pass reported how many, the list now holds them: once more
+                lp_enum_stats first{};
+                if (stats_out) first = *stats_out;
+                rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
+                if (stats_out) {
+                    stats_out->kernel_ms += first.kernel_ms;
+                    stats_out->launches += first.launches;
+                }
+            }
             if (rc == kEnumListOverflow) {
-                // more feasible subsets than the list holds.  Every listed subset is re-solved for its
+                // no memory for a list that long (or LP_ENUM_LIST_CAP pins its size).  Without the list
+                // every feasible subset would be solved again from scratch for its
                 // objective, so once more than half of the range is feasible (a degenerate LP) the
                 // shared prefixes save nothing: that range goes to the direct kernel as a whole;
                 // otherwise it is enumerated in sub-ranges, one list at a time.

@@ -517,19 +517,21 @@ int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best) {
 // Queues, behind the kernels that fill the feasible list, its evaluation and the tie rule against
 // the list's own best score (tolerance tol) — no host round trip: the caller synchronises once and
 // finds best_key and first_rank in the result block.
-int lp_enum_queue_list_tail(lp_enum_problem* p, double tol) {
+int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* records) {
     lp_context* ctx = p->ctx;
     const EnumDev& d = p->dev;
     const PrefixDev& pd = p->prefix;
     const size_t shm = enum_smem_bytes(d);
     const unsigned grid = (unsigned)ctx->num_cus * 2;
-    if (d.m <= 16)
+    if (records && getenv("LP_ENUM_EVAL_DIRECT") == nullptr)   // (A/B: from-scratch solves)
+        lp_enum_queue_record_eval(p, records);
+    else if (d.m <= 16)
         hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,
                            (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores);
     else
         hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,
                            (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores);
-    hipLaunchKernelGGL(k_enum_list_first, 64, 256, 0, ctx->stream, d, pd.list, 0ULL,
+    hipLaunchKernelGGL(k_enum_list_first, (unsigned)ctx->num_cus * 4, 256, 0, ctx->stream, d, pd.list, 0ULL,
                        (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores, 0.0, tol);
     return LP_OPTIMAL;
 }

@@ -54,9 +54,23 @@ constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so th
 // used ones at KD..m-1 — so every row index below is a compile-time constant (LDS reads with
 // immediate offsets, pairs of rows per instruction) and U / used are ignored; the wave is then
 // uniform (one tableau per wave).  Returns 0 feasible, 1 infeasible, 2 singular.
-template <int KD, int STRIDE, bool PERM>
+//
+// OBJ (list evaluation, records in HBM): every row is finished — no early exit — and obj->z receives
+// the objective, summed as the direct kernel sums it (enum_direct.hip: subset_objective): one fma per
+// basis column in ascending column order, i.e. the prefix's columns (depth order), then c[0..KD-1].
+struct LeafObj {
+    const double* cost;           // objective coefficients by original column
+    const unsigned char* prow;    // pivot row / column of each prefix depth (NodeMeta)
+    const unsigned char* pcol;
+    int D;                        // depth of the record
+    int col0;                     // original column of tableau column 0
+    double z;
+};
+
+template <int KD, int STRIDE, bool PERM, bool OBJ = false>
 __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
-                                            unsigned used, double minp0, double maxp0, int m) {
+                                            unsigned used, double minp0, double maxp0, int m,
+                                            LeafObj* obj = nullptr) {
     // ---- phase 1: unused rows x chosen columns
     double E[KD][KD], H[KD];
     // PERM (tableau in LDS): step 0's pivot row is chosen BEFORE the rows are loaded — the entries
@@ -212,10 +226,12 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
     bool feas = (xa >= -1e-9) && (xb >= -1e-9);
     // the rows pivoted in phase 1: back-substitution
+    double xr[OBJ ? KD - 2 : 1];
 #pragma unroll
     for (int r = 0; r < KD - 2; ++r) {
         const double x = fma(-E[r][KD - 1], xb, fma(-E[r][KD - 2], xa, H[r]));
         feas = feas && (x >= -1e-9);
+        if constexpr (OBJ) xr[r] = x;
     }
     // ---- phase 2: rows already used by the prefix, one at a time
     // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
@@ -237,8 +253,17 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         const double x = fma(-v[KD - 1], xb, fma(-v[KD - 2], xa, h));
         feas = feas && (!has || x >= -1e-9);
         alive = alive && feas;
+        return x;
     };
-    if constexpr (PERM) {
+    if constexpr (OBJ) {
+        double z = 0.0;
+        for (int k = 0; k < obj->D; ++k) z = fma(obj->cost[obj->pcol[k]], one_row(obj->prow[k], true), z);
+#pragma unroll
+        for (int r = 0; r < KD - 2; ++r) z = fma(obj->cost[obj->col0 + c[r]], xr[r], z);
+        z = fma(obj->cost[obj->col0 + c[KD - 2]], xa, z);
+        z = fma(obj->cost[obj->col0 + c[KD - 1]], xb, z);
+        obj->z = z;
+    } else if constexpr (PERM) {
         for (int i = KD; i < m && __any(alive); ++i) one_row(i, true);
     } else {
         while (__any(alive && rows != 0u)) {
@@ -477,9 +502,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     };
     double pre[NLOAD];
     NodeMeta pmB;
-    int chunkB = 0, childB = 0, roffB = 0;
+    int chunkB = 0, childB = 0, roffB = 0, recB = 0;
     auto fetch = [&](int item) {   // issue the loads of item's record (no use of the data here)
         const int4 it = items[item];
+        recB = it.x;
         childB = it.y;
         chunkB = it.z;
         roffB = it.w;
@@ -498,7 +524,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     for (;;) {
         if (itemB >= nitems) break;
         // ---- item B becomes the current item: registers -> LDS slice (odd column stride)
-        const int chunk = chunkB, child = childB, roff = roffB;
+        const int chunk = chunkB, child = childB, roff = roffB, rec = recB;
         const NodeMeta pm = pmB;
         double* tab = s_tab[wave * 2 + buf];
 #pragma unroll
@@ -633,7 +659,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 } else {
                     ++cntF;
                     const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-                    if (at < pd.list_cap) pd.list[at] = rank;
+                    if (at < pd.list_cap) {
+                        pd.list[at] = rank;
+                        pd.list_rec[at] = rec;
+                    }
                 }
             }
             }
@@ -705,7 +734,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 } else {
                     ++cntF;
                     const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-                    if (at < pd.list_cap) pd.list[at] = rank;
+                    if (at < pd.list_cap) {
+                        pd.list[at] = rank;
+                        pd.list_rec[at] = rec;
+                    }
                 }
             }
         } else {
@@ -725,7 +757,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             } else {
                 ++cntF;
                 const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-                if (at < pd.list_cap) pd.list[at] = rank;
+                if (at < pd.list_cap) {
+            pd.list[at] = rank;
+            pd.list_rec[at] = rec;
+        }
             }
         }
         }
@@ -791,7 +826,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     }
     if (verdict == 0) {
         const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-        if (at < pd.list_cap) pd.list[at] = rank;
+        if (at < pd.list_cap) {
+            pd.list[at] = rank;
+            pd.list_rec[at] = rec;
+        }
     }
     cnt[0] += verdict == 0;
     cnt[1] += verdict == 1;
@@ -809,7 +847,85 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
 }
 
+// Objectives of the listed (feasible) subsets from the depth m-7 records they were found under: one
+// lane per list entry.  The lane unranks its 7 remaining columns inside the record, repeats the
+// leaf's arithmetic (leaf_verdict<7, PG, false, OBJ>: the operations, operand for operand, of the
+// direct solver, so the score is the one k_enum_eval_list would produce) and keeps every row's
+// value for the objective — ~1/15 of the price of a from-scratch m x m solve per entry, which is
+// what a degenerate LP (every non-singular basis feasible: hundreds of millions of entries) pays.
+__global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, PrefixDev pd,
+                                                                     const double* __restrict__ roots,
+                                                                     double* __restrict__ scores) {
+    constexpr int KD = 7;
+    __shared__ unsigned int s_bin[(NMX + KD + 2) * (KD + 1)];   // C(r, k), r <= NMX + KD + 1, k <= KD
+    __shared__ double s_cost[2 * PG];                           // n <= 32 on this path
+    __shared__ unsigned long long s_best;
+    const int m = d.m, n = d.n, D = m - KD;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
+        const int r = k / (KD + 1), kk = k - r * (KD + 1);
+        s_bin[k] = (unsigned int)d.binom[r * kBinomK + kk];
+    }
+    if (tid < n) s_cost[tid] = d.c[tid];
+    if (tid == 0) s_best = lp_f64_key(-INFINITY);
+    __syncthreads();
+    const unsigned long long count = *pd.list_count < pd.list_cap ? *pd.list_count : pd.list_cap;
+    double best = -INFINITY;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * LEAF_THREADS + tid; e < count;
+         e += (unsigned long long)gridDim.x * LEAF_THREADS) {
+        const unsigned long long rank = pd.list[e];
+        const double* Q = roots + (size_t)pd.list_rec[e] * rec_doubles(n, D);
+        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(Q + (size_t)PG * (n - D + 1));
+        const int last = pm->last_col;
+        const int R = n - 1 - last;
+        // the 7 remaining columns: lexicographic unranking inside the R selectable ones
+        unsigned int left = (unsigned int)(rank - pm->rank_base);
+        int c[KD];
+        int j = 0;
+#pragma unroll
+        for (int t = 0; t < KD; ++t) {
+            for (;; ++j) {
+                const unsigned int cnt = s_bin[(R - 1 - j) * (KD + 1) + (KD - 1 - t)];
+                if (left < cnt) break;
+                left -= cnt;
+            }
+            c[t] = j++;
+        }
+        const unsigned umask = pm->used_mask;
+        int U[KD];
+        unsigned free_rows = ~umask & ((1u << m) - 1u);
+#pragma unroll
+        for (int r = 0; r < KD; ++r) {
+            U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
+            free_rows &= free_rows - 1u;
+        }
+        LeafObj obj;
+        obj.cost = s_cost;
+        obj.prow = pm->prow;
+        obj.pcol = pm->pcol;
+        obj.D = D;
+        obj.col0 = last + 1;
+        obj.z = 0.0;
+        const double* tab = Q + (size_t)(last + 1 - D) * PG;   // column q = column last+1+q
+        const int verdict = leaf_verdict<KD, PG, false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
+        // (listed subsets are feasible by construction; a verdict mismatch would be a bug and shows
+        // up as -inf here)
+        const double score = verdict == 0 ? (d.maximize ? obj.z : -obj.z) : -INFINITY;
+        scores[e] = score;
+        best = fmax(best, score);
+    }
+    if (best > -INFINITY) atomicMax(&s_best, lp_f64_key(best));
+    __syncthreads();
+    if (tid == 0 && s_best != lp_f64_key(-INFINITY)) atomicMax(&d.result->best_key, s_best);
+}
+
 }  // namespace
+
+void lp_enum_queue_record_eval(lp_enum_problem* p, const double* roots) {
+    lp_context* ctx = p->ctx;
+    hipLaunchKernelGGL(k_enum_eval_records, (unsigned)ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev,
+                       p->prefix, roots, p->prefix.scores);
+}
 
 // Second phase of the shared-prefix pass over the records of the last breadth-first level
 // (`roots`, count in level_counts[level], at most `bound`): depth m-7 records (fused = true: the

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             cm.maxp = maxp;
             cm.last_col = a;
             cm.used_mask = pm.used_mask | (1u << p);
-            for (int q = 0; q < 8; ++q) cm.pad[q] = 0;
+            for (int q = 0; q < 16; ++q) {
+                cm.prow[q] = q == t ? (unsigned char)p : pm.prow[q];
+                cm.pcol[q] = q == t ? (unsigned char)a : pm.pcol[q];
+            }
             *cmeta = cm;
         }
     }
@@ -244,7 +247,10 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
         cm.maxp = maxp;
         cm.last_col = a;
         cm.used_mask = pm.used_mask | (1u << p);
-        for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+        for (int k = 0; k < 16; ++k) {
+            cm.prow[k] = k == t ? (unsigned char)p : pm.prow[k];
+            cm.pcol[k] = k == t ? (unsigned char)a : pm.pcol[k];
+        }
         *cmeta = cm;
     }
 }
@@ -277,7 +283,7 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
         cm.maxp = 0.0;
         cm.last_col = -1;
         cm.used_mask = 0u;
-        for (int k = 0; k < 8; ++k) cm.pad[k] = 0;
+        for (int k = 0; k < 16; ++k) cm.prow[k] = cm.pcol[k] = 0;
         *reinterpret_cast<NodeMeta*>(dst + (size_t)PG * (d.n + 1)) = cm;
     }
 }
@@ -403,7 +409,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     // range's own best score (what a sharded run asks next): queued behind the leaf kernels
     constexpr double kSpecTol = 1e-9;   // Solver::EPS, the tolerance dist.py / EnumerationSolver use
     p->spec_valid = false;
-    lp_enum_queue_list_tail(p, kSpecTol);
+    lp_enum_queue_list_tail(p, kSpecTol, fused ? p->prefix_buf[cur] : nullptr);
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -413,9 +419,16 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     for (int t = 1; t <= D0; ++t)
         if (p->h_level_counts[t] > caps[t]) return LP_ITER_LIMIT;  // a level buffer was too small
     if (*p->h_overflow != 0) return LP_ITER_LIMIT;  // fall back
-    if (*p->h_list_count > pd.list_cap) return kEnumListOverflow;   // the caller splits the range
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    if (*p->h_list_count > pd.list_cap) {   // the caller grows the list or splits the range
+        if (stats) {
+            stats->kernel_ms = ms;
+            stats->subsets = end - begin;
+            stats->launches = launches;
+        }
+        return kEnumListOverflow;
+    }
     const uint64_t nfeas = *p->h_list_count;
     double best = -INFINITY;
     if (nfeas) best = lp_key_f64(p->h_result->best_key);

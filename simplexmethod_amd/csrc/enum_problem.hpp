@@ -53,6 +53,7 @@ struct PrefixDev {
     int* overflow;                    // != 0: a buffer was too small, the caller falls back
     int* root_cursor;                 // [2] work cursors (regular / thin leaf kernel, sweep groups)
     unsigned long long* list;         // ranks of feasible subsets
+    int* list_rec;                    // record (last breadth-first level) each entry was found under
     unsigned long long* list_count;
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
@@ -126,8 +127,10 @@ int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* su
 int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 // smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
-// evaluation + tie rule against the list's own best, queued without a host round trip
-int lp_enum_queue_list_tail(lp_enum_problem* p, double tol);
+// evaluation + tie rule against the list's own best, queued without a host round trip; records !=
+// null: the depth m-7 records of the pass (the entries are evaluated from them, enum_leaf.hip)
+int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* records);
+void lp_enum_queue_record_eval(lp_enum_problem* p, const double* records);
 
 // enum_leaf.hip: one lane per subset below the records of the last breadth-first level
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,

@@ -18,7 +18,8 @@ struct NodeMeta {  // 64 bytes, stored behind the columns of a record
     double minp, maxp;             // smallest / largest |pivot| so far
     int last_col;                  // last chosen column (-1 at the root)
     unsigned used_mask;            // bit i: row i already used as a pivot row
-    int pad[8];
+    unsigned char prow[16];        // prow[k], pcol[k]: pivot row and chosen column of depth k < the node's
+    unsigned char pcol[16];        // depth (the objective of a listed subset is summed in this order)
 };
 static_assert(sizeof(NodeMeta) == META * 8, "NodeMeta must be 64 bytes");
 

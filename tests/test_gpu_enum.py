@@ -512,6 +512,32 @@ def test_feasible_list_spills_into_subranges(ctx, monkeypatch):
         p.free()
 
 
+def test_feasible_list_grows_and_is_evaluated_from_records(ctx, monkeypatch):
+    """The same degenerate LPs on the default route: the pass that overflows the list reports the number
+    of feasible subsets, the list is re-allocated to hold them and the pass runs once more; every entry's
+    objective then comes from the depth m-7 record it was found under (k_enum_eval_records).  Counts,
+    optimum and the tie rule's rank against the oracle, and bit-identical to the from-scratch evaluation
+    of the direct kernel."""
+    monkeypatch.setenv("LP_ENUM_LIST_START", "300")
+    for seed, m, n, zero_rows in [(71, 8, 18, 8), (72, 8, 18, 5), (73, 10, 20, 10), (74, 7, 17, 7), (75, 12, 22, 9)]:
+        A, b, c, _ = lpcases.random_lp(seed, m, n)
+        b = b.copy()
+        b[:zero_rows] = 0.0
+        total = o.binom(n, m)
+        ref = o.enum_range(A, b, c, True, 0, total)
+        assert ref[2][0] > 300
+        p = ctx.enum_problem(A, b, c, True)
+        got = p.range(0, total, capi.ENUM_PREFIX)
+        assert got[:3] == ref, (seed, m, n)
+        assert p.first_within(0, total, ref[1]) == o.enum_first_within(A, b, c, True, 0, total, ref[1])
+        assert p.range(0, total, capi.ENUM_DIRECT)[:3] == ref
+        lo, hi = total // 7, total - total // 5
+        ref2 = o.enum_range(A, b, c, True, lo, hi)
+        assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref2
+        assert p.first_within(lo, hi, ref2[1], 1e-3) == o.enum_first_within(A, b, c, True, lo, hi, ref2[1], 1e-3)
+        p.free()
+
+
 def test_fuzz_small_structured_problems(ctx):
     """150 small problems with integer data in {-1, 0, 1, 2} (ties, zero pivots, duplicate columns
     everywhere), both senses: counts, optimum and the tie rule's rank against the oracle — on the
