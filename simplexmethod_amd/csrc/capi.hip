@@ -1,6 +1,8 @@
 // capi.hip — the extern "C" boundary (include/simplexmethod_amd.h): argument checks that
 // mirror the reference's constructors, uploads/downloads, and dispatch to the kernels.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 
 #include "batched_problem.hpp"
 #include "enum_problem.hpp"
@@ -488,6 +490,16 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
     std::vector<int> N((size_t)m);
     int it[3] = {0, 0, 0};
     if (iters_out) std::memcpy(iters_out, it, sizeof(it));
+    // LP_TWO_PHASE_TRACE=1: wall time of each stage on stderr (diagnostic)
+    const bool trace = getenv("LP_TWO_PHASE_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto stage = [&](const char* name) {
+        if (!trace) return;
+        const auto t = now();
+        fprintf(stderr, "[two_phase] %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // make_b_nonneg (:61-68) and createAuxiliaryProblem (:70-95)
     for (int i = 0; i < m; ++i) {
         const bool flip = b[i] < -eps;
@@ -497,14 +509,18 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
     }
     for (int j = n; j < na; ++j) c1[j] = 1.0;
     for (int t = 0; t < m; ++t) N[t] = n + t;
+    stage("auxiliary problem (host)");
     // ---- phase I: minimise the sum of the artificials
     lp_simplex_problem* p = nullptr;
     int rc = lp_simplex_upload(ctx, A1.data(), m, na, b1.data(), c1.data(), N.data(), 0, na, &p);
     if (rc) return rc;
+    stage("upload");
     lp_simplex_stats st;
     rc = lp_simplex_run(p, eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
     it[0] = st.pivots;
+    stage("phase I run");
     if (rc == LP_OPTIMAL) rc = lp_simplex_download(p, xa.data(), N.data(), nullptr, nullptr, nullptr, 0, nullptr);
+    stage("phase I download");
     if (rc == LP_OPTIMAL) {
         double sum = 0.0;  // :347-350
         for (int i = 0; i < m; ++i) sum += xa[(size_t)n + i];
@@ -528,10 +544,13 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
     }
     // ---- phase II (:383-404) continues on the phase-I tableau: original costs priced out over the
     // current basis, artificial columns barred — no re-inversion of the basis from [A' | b']
+    stage("drive-out");
     if (rc == LP_OPTIMAL) rc = lp_simplex_phase2_costs(p, c, n, maximize, n_orig);
+    stage("phase II costs");
     if (rc == LP_OPTIMAL) {
         rc = lp_simplex_run(p, eps, max_iter, LP_SIMPLEX_ALGO_AUTO, &st);
         it[2] = st.pivots;
+        stage("phase II run");
         if (rc == LP_OPTIMAL)
             rc = lp_simplex_download(p, x_out, N.data(), obj_out, nullptr, nullptr, 0, nullptr);
         else if (rc > 0)
@@ -539,7 +558,9 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
     } else if (rc == LP_SINGULAR || rc == LP_INFEASIBLE) {
         (void)lp_simplex_download(p, nullptr, N.data(), nullptr, nullptr, nullptr, 0, nullptr);
     }
+    stage("phase II download");
     lp_simplex_free(p);
+    stage("free");
     if (basis_out) std::memcpy(basis_out, N.data(), sizeof(int) * (size_t)m);
     if (iters_out) std::memcpy(iters_out, it, sizeof(it));
     return rc;

@@ -237,7 +237,7 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     // (a subset survives phase 1 with probability ~2^-8, so the loop below usually ends
     // after a row or two: it stops as soon as no lane of the wave is still feasible)
     bool alive = !sing && feas;
-    unsigned rows = used & ((1u << m) - 1u);
+    unsigned rows = used & (m >= 32 ? ~0u : ((1u << m) - 1u));
     auto one_row = [&](int i, bool has) {
         double v[KD];
 #pragma unroll
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
                 for (int t = 0; t < KD; ++t) c[t] = (R - R8) + t + ((R8 == THIN_TAIL && t >= 7 - j) ? 1 : 0);
                 const unsigned umask = pm->used_mask;
                 int U[KD];
-                unsigned free_rows = ~umask & ((1u << m) - 1u);
+                unsigned free_rows = ~umask & (m >= 32 ? ~0u : ((1u << m) - 1u));
 #pragma unroll
                 for (int r = 0; r < KD; ++r) {
                     U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
@@ -842,6 +842,150 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
         if ((tid & 63) == 0 && c) atomicAdd(&s_cnt[v], (unsigned long long)c);
+    }
+    __syncthreads();
+    if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The general leaf kernel: ANY record height (PGT = 16 or 32 rows) and any number of selectable
+// columns.  The three kernels above are tuned for m <= 16, n - m <= 16 (subset tables, LDS slices
+// sized for 24 columns, 16-lane cooperative pivots); shapes outside that box used to fall to the
+// from-scratch solver of enum_direct.hip at ~2 ns per subset.  Here a wave takes an item = (depth
+// m-7 record, run of consecutive subsets of its C(R,7)); every lane unranks the first subset of its
+// own contiguous share once (binomials from LDS), then walks lexicographic successors, reading the
+// record where it lies (L1/L2: a record is at most 40 x 32 doubles) — leaf_verdict<7, PGT, false>,
+// the arithmetic of the thin kernel.
+constexpr int kGenChunk = 2048;   // subsets per item (32 per lane)
+constexpr int NMXW = 32;          // max n - m of the general path
+
+template <int PGT>
+__device__ __forceinline__ size_t rec_doubles_g(int n, int t) { return (size_t)PGT * (n - t + 1) + META; }
+
+template <int PGT>
+__global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev pd,
+                                                            const double* __restrict__ roots, int root_level,
+                                                            int root_cap, unsigned long long begin,
+                                                            unsigned long long end) {
+    constexpr int KD = 7;
+    const int n = d.n, m = d.m, D = m - KD;
+    const int nrec = min(pd.level_counts[root_level], root_cap);
+    const int rec = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long lo0 = 0, hi0 = 0;
+    if (rec < nrec) {
+        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(roots + (size_t)rec * rec_doubles_g<PGT>(n, D) +
+                                                               (size_t)PGT * (n - D + 1));
+        const int last = pm->last_col;
+        const int R = n - 1 - last;
+        if (last != kHole && R >= KD) {
+            const unsigned long long rb = pm->rank_base, L = binom(d, R, KD);
+            const unsigned long long lo = rb > begin ? rb : begin, hi = rb + L < end ? rb + L : end;
+            if (hi > lo) {
+                lo0 = lo - rb;
+                hi0 = hi - rb;
+            }
+        }
+    }
+    const int nitem = (int)((hi0 - lo0 + kGenChunk - 1) / kGenChunk);
+    int at = nitem ? atomicAdd(&pd.item_count[0], nitem) : 0;
+    for (int k = 0; k < nitem; ++k, ++at) {
+        const unsigned long long lo = lo0 + (unsigned long long)k * kGenChunk;
+        const unsigned long long cnt = hi0 - lo < (unsigned long long)kGenChunk ? hi0 - lo : (unsigned long long)kGenChunk;
+        if (at < pd.item_cap) pd.items[at] = make_int4(rec, (int)lo, (int)cnt, 0);
+    }
+}
+
+template <int PGT>
+__global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
+                                                                       const double* __restrict__ roots) {
+    constexpr int KD = 7;
+    __shared__ unsigned int s_bin[(NMXW + KD + 2) * (KD + 1)];   // C(r, k), r <= NMXW + KD + 1, k <= KD
+    __shared__ unsigned long long s_cnt[3];
+    const int m = d.m, n = d.n, D = m - KD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < (NMXW + KD + 2) * (KD + 1); k += LEAF_THREADS) {
+        const int r = k / (KD + 1), kk = k - r * (KD + 1);
+        s_bin[k] = (unsigned int)d.binom[r * kBinomK + kk];
+    }
+    if (tid < 3) s_cnt[tid] = 0ULL;
+    __syncthreads();
+    const int nitems = min(pd.item_count[0], pd.item_cap);
+    unsigned int cnt[3] = {0u, 0u, 0u};
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(&pd.root_cursor[0], 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const int4 it = pd.items[item];
+        const int rec = it.x;
+        const double* Q = roots + (size_t)rec * rec_doubles_g<PGT>(n, D);
+        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(Q + (size_t)PGT * (n - D + 1));
+        const int last = pm->last_col;
+        const int R = n - 1 - last;
+        const unsigned umask = pm->used_mask;
+        const unsigned long long rb = pm->rank_base;
+        const double minp0 = pm->minp, maxp0 = pm->maxp;
+        int U[KD];
+        unsigned free_rows = ~umask & (m >= 32 ? ~0u : ((1u << m) - 1u));
+#pragma unroll
+        for (int r = 0; r < KD; ++r) {
+            U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
+            free_rows &= free_rows - 1u;
+        }
+        const double* tab = Q + (size_t)(last + 1 - D) * PGT;   // column q = column last+1+q
+        // this lane's share: K consecutive subsets from `mine`
+        const unsigned int total = (unsigned int)it.z;
+        const unsigned int K = (total + 63u) / 64u;
+        const unsigned int mine = (unsigned int)it.y + (unsigned int)lane * K;
+        const unsigned int have = (unsigned int)lane * K < total ? min(K, total - (unsigned int)lane * K) : 0u;
+        int c[KD];
+        {
+            unsigned int left = have ? mine : 0u;
+            int j = 0;
+#pragma unroll
+            for (int t = 0; t < KD; ++t) {
+                for (;; ++j) {
+                    const unsigned int cn = s_bin[(R - 1 - j) * (KD + 1) + (KD - 1 - t)];
+                    if (left < cn) break;
+                    left -= cn;
+                }
+                c[t] = j++;
+            }
+        }
+        for (unsigned int k = 0; k < K; ++k) {
+            if (k < have) {
+                const int verdict = leaf_verdict<KD, PGT, false>(tab, c, R, U, umask, minp0, maxp0, m);
+                if (verdict == 0) {
+                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                    if (at < pd.list_cap) {
+                        pd.list[at] = rb + mine + k;
+                        pd.list_rec[at] = rec;
+                    }
+                }
+                cnt[0] += verdict == 0;
+                cnt[1] += verdict == 1;
+                cnt[2] += verdict == 2;
+                // lexicographic successor inside {0 .. R-1}
+                int tpos = -1;
+#pragma unroll
+                for (int t = 0; t < KD; ++t)
+                    if (c[t] < R - KD + t) tpos = t;
+#pragma unroll
+                for (int t = 0; t < KD; ++t) {
+                    if (t == tpos)
+                        c[t] += 1;
+                    else if (t > tpos && t > 0)
+                        c[t] = c[t - 1] + 1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        unsigned int x = cnt[v];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        if (lane == 0 && x) atomicAdd(&s_cnt[v], (unsigned long long)x);
     }
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
@@ -893,7 +1037,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
         }
         const unsigned umask = pm->used_mask;
         int U[KD];
-        unsigned free_rows = ~umask & ((1u << m) - 1u);
+        unsigned free_rows = ~umask & (m >= 32 ? ~0u : ((1u << m) - 1u));
 #pragma unroll
         for (int r = 0; r < KD; ++r) {
             U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
@@ -958,7 +1102,11 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     // persistent waves (items are dealt dynamically): as many blocks as are resident
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
-    if (fused) {
+    if (fused && getenv("LP_ENUM_GENERIC")) {   // (A/B: the general leaf kernel on a shape the tuned ones take)
+        hipLaunchKernelGGL(k_enum_generic_items<PG>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd, roots,
+                           level, bound, b, e);
+        hipLaunchKernelGGL(k_enum_generic_leaves<PG>, ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
+    } else if (fused) {
         // The three leaf kernels are independent of each other (own item table / work cursor, results
         // through atomics), and the thin kernel does not even need the item tables: they run on three
         // streams, so that the thin kernel overlaps the item builder and every kernel's tail (persistent
