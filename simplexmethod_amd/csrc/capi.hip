@@ -889,27 +889,44 @@ static bool enum_list_grow(lp_enum_problem* p, uint64_t nfeas) {
     return false;
 }
 
-// Shared-prefix enumeration of a range whose feasible subsets overflow the list: sub-ranges sized
-// from the feasible count the overflowing pass reported, split again where one still overflows.
-// Counts add, the best score is the maximum; every sub-range keeps its best score for pass 2.
-static int enum_prefix_chunked(lp_enum_problem* p, uint64_t begin, uint64_t end, uint64_t nfeas_hint,
+// One shared-prefix pass over [begin, end).  A list that overflows (a degenerate LP: up to every
+// non-singular basis is feasible) is re-allocated for the count the pass reported, if the device has
+// the memory, and the pass runs once more.
+static int enum_prefix_pass(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score, uint64_t counts[3],
+                            lp_enum_stats* stats) {
+    int rc = lp_enum_prefix_range(p, begin, end, score, counts, stats);
+    if (rc == kEnumListOverflow && enum_list_grow(p, *p->h_list_count)) {
+        lp_enum_stats first{};
+        if (stats) first = *stats;
+        rc = lp_enum_prefix_range(p, begin, end, score, counts, stats);
+        if (stats) {
+            stats->kernel_ms += first.kernel_ms;
+            stats->launches += first.launches;
+        }
+    }
+    return rc;
+}
+
+// Shared-prefix enumeration of a range in sub-ranges: because its depth m-7 nodes do not fit the level
+// buffers (large shapes: C(n-7, m-7) records), or because its feasible subsets overflow a list that
+// cannot grow.  A sub-range that still does not fit is split again.  Counts add, the best score is
+// the maximum; every sub-range keeps its best score for pass 2.
+static int enum_prefix_chunked(lp_enum_problem* p, uint64_t begin, uint64_t end, uint64_t parts0,
                                double* score_best, uint64_t counts[3], lp_enum_stats* stats) {
-    const uint64_t cap = p->prefix.list_cap;
     p->pchunks.clear();
     p->pchunks_valid = false;
-    struct Part { uint64_t b, e, hint; };
+    struct Part { uint64_t b, e; };
     std::vector<Part> todo;
-    auto split = [&](uint64_t b, uint64_t e, uint64_t hint) {   // pushes in DEscending order (stack)
-        uint64_t parts = hint / (cap / 2) + 1;
+    auto split = [&](uint64_t b, uint64_t e, uint64_t parts) {   // pushes in DEscending order (stack)
         if (parts < 2) parts = 2;
         if (parts > e - b) parts = e - b;
         for (uint64_t k = parts; k-- > 0;) {
             const uint64_t pb = b + (e - b) / parts * k + std::min<uint64_t>(k, (e - b) % parts);
             const uint64_t pe = b + (e - b) / parts * (k + 1) + std::min<uint64_t>(k + 1, (e - b) % parts);
-            todo.push_back({pb, pe, hint / parts + 1});
+            todo.push_back({pb, pe});
         }
     };
-    split(begin, end, nfeas_hint);
+    split(begin, end, parts0);
     double best = -INFINITY;
     float ms = 0.f;
     int launches = 0;
@@ -920,13 +937,17 @@ static int enum_prefix_chunked(lp_enum_problem* p, uint64_t begin, uint64_t end,
         double sc = -INFINITY;
         uint64_t cn[3] = {0, 0, 0};
         lp_enum_stats st{};
-        int rc = lp_enum_prefix_range(p, part.b, part.e, &sc, cn, &st);
+        int rc = enum_prefix_pass(p, part.b, part.e, &sc, cn, &st);
         if (rc == kEnumListOverflow && part.e - part.b > 1 && *p->h_list_count * 2 <= part.e - part.b) {
-            split(part.b, part.e, *p->h_list_count);
+            split(part.b, part.e, *p->h_list_count / (p->prefix.list_cap / 2) + 1);
+            continue;
+        }
+        if (rc == kEnumRangeTooWide && part.e - part.b > 1) {
+            split(part.b, part.e, p->split_hint + 1);
             continue;
         }
         bool direct = false;
-        if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow) {   // no memory for the level buffers
+        if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow || rc == kEnumRangeTooWide) {   // no memory for the level buffers
             rc = lp_enum_direct_range(p, part.b, part.e, &sc, cn, &st);
             direct = true;
         }
@@ -978,29 +999,24 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     switch (algo) {
         case LP_ENUM_ALGO_PREFIX:
             if (!lp_enum_prefix_supported(p))
-                LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 16 and 2 <= n-m <= 16");
-            rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
-            if (rc == kEnumListOverflow && enum_list_grow(p, *p->h_list_count)) {
-                // more feasible subsets than the list held (a degenerate LP: up to every non-singular
-                // basis is feasible); the pass reported how many, the list now holds them: once more
-                lp_enum_stats first{};
-                if (stats_out) first = *stats_out;
-                rc = lp_enum_prefix_range(p, rank_begin, rank_end, &score, counts, stats_out);
-                if (stats_out) {
-                    stats_out->kernel_ms += first.kernel_ms;
-                    stats_out->launches += first.launches;
-                }
-            }
-            if (rc == kEnumListOverflow) {
+                LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 32 and 2 <= n-m <= 32 (m >= 7 beyond 16 x 16)");
+            rc = enum_prefix_pass(p, rank_begin, rank_end, &score, counts, stats_out);
+            if (rc == kEnumRangeTooWide) {
+                // more depth m-7 nodes than the level buffers hold: sub-ranges, a quarter over the
+                // exact ratio (equal rank counts do not hold equal node counts)
+                rc = enum_prefix_chunked(p, rank_begin, rank_end, p->split_hint + p->split_hint / 4 + 1, &score, counts,
+                                         stats_out);
+            } else if (rc == kEnumListOverflow) {
                 // no memory for a list that long (or LP_ENUM_LIST_CAP pins its size).  Without the list
-                // every feasible subset would be solved again from scratch for its
-                // objective, so once more than half of the range is feasible (a degenerate LP) the
-                // shared prefixes save nothing: that range goes to the direct kernel as a whole;
-                // otherwise it is enumerated in sub-ranges, one list at a time.
+                // every feasible subset would be solved again from scratch for its objective, so once
+                // more than half of the range is feasible the shared prefixes save nothing: that range
+                // goes to the direct kernel as a whole; otherwise it is enumerated in sub-ranges, one
+                // list at a time.
                 if (*p->h_list_count * 2 > rank_end - rank_begin)
                     rc = LP_ITER_LIMIT;
                 else
-                    rc = enum_prefix_chunked(p, rank_begin, rank_end, *p->h_list_count, &score, counts, stats_out);
+                    rc = enum_prefix_chunked(p, rank_begin, rank_end, *p->h_list_count / (p->prefix.list_cap / 2) + 1,
+                                             &score, counts, stats_out);
             }
             if (rc != LP_ITER_LIMIT) break;
             // no memory for the level buffers of this problem: direct path
@@ -1046,9 +1062,9 @@ int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_
             } else {
                 double sc;
                 uint64_t cn[3];
-                rc = lp_enum_prefix_range(p, ch.begin, ch.end, &sc, cn, nullptr);
+                rc = enum_prefix_pass(p, ch.begin, ch.end, &sc, cn, nullptr);
                 if (rc == LP_OPTIMAL) rc = lp_enum_list_first(p, star, tol, &first);
-                else if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow)
+                else if (rc == LP_ITER_LIMIT || rc == kEnumListOverflow || rc == kEnumRangeTooWide)
                     rc = lp_enum_direct_first(p, ch.begin, ch.end, star, tol, &first);
             }
             if (rc) return rc;

@@ -860,9 +860,6 @@ constexpr int kGenChunk = 2048;   // subsets per item (32 per lane)
 constexpr int NMXW = 32;          // max n - m of the general path
 
 template <int PGT>
-__device__ __forceinline__ size_t rec_doubles_g(int n, int t) { return (size_t)PGT * (n - t + 1) + META; }
-
-template <int PGT>
 __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev pd,
                                                             const double* __restrict__ roots, int root_level,
                                                             int root_cap, unsigned long long begin,
@@ -873,7 +870,7 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
     const int rec = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long lo0 = 0, hi0 = 0;
     if (rec < nrec) {
-        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(roots + (size_t)rec * rec_doubles_g<PGT>(n, D) +
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(roots + (size_t)rec * rec_doubles_g<PGT>(n, D) +
                                                                (size_t)PGT * (n - D + 1));
         const int last = pm->last_col;
         const int R = n - 1 - last;
@@ -919,7 +916,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         const int4 it = pd.items[item];
         const int rec = it.x;
         const double* Q = roots + (size_t)rec * rec_doubles_g<PGT>(n, D);
-        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(Q + (size_t)PGT * (n - D + 1));
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)PGT * (n - D + 1));
         const int last = pm->last_col;
         const int R = n - 1 - last;
         const unsigned umask = pm->used_mask;
@@ -997,16 +994,17 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
 // direct solver, so the score is the one k_enum_eval_list would produce) and keeps every row's
 // value for the objective — ~1/15 of the price of a from-scratch m x m solve per entry, which is
 // what a degenerate LP (every non-singular basis feasible: hundreds of millions of entries) pays.
+template <int PGT>
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, PrefixDev pd,
                                                                      const double* __restrict__ roots,
                                                                      double* __restrict__ scores) {
     constexpr int KD = 7;
-    __shared__ unsigned int s_bin[(NMX + KD + 2) * (KD + 1)];   // C(r, k), r <= NMX + KD + 1, k <= KD
-    __shared__ double s_cost[2 * PG];                           // n <= 32 on this path
+    __shared__ unsigned int s_bin[(NMXW + KD + 2) * (KD + 1)];   // C(r, k), r <= NMXW + KD + 1, k <= KD
+    __shared__ double s_cost[kEnumMaxN];
     __shared__ unsigned long long s_best;
     const int m = d.m, n = d.n, D = m - KD;
     const int tid = threadIdx.x;
-    for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
+    for (int k = tid; k < (NMXW + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_bin[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
@@ -1018,8 +1016,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
     for (unsigned long long e = (unsigned long long)blockIdx.x * LEAF_THREADS + tid; e < count;
          e += (unsigned long long)gridDim.x * LEAF_THREADS) {
         const unsigned long long rank = pd.list[e];
-        const double* Q = roots + (size_t)pd.list_rec[e] * rec_doubles(n, D);
-        const NodeMeta* pm = reinterpret_cast<const NodeMeta*>(Q + (size_t)PG * (n - D + 1));
+        const double* Q = roots + (size_t)pd.list_rec[e] * rec_doubles_g<PGT>(n, D);
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)PGT * (n - D + 1));
         const int last = pm->last_col;
         const int R = n - 1 - last;
         // the 7 remaining columns: lexicographic unranking inside the R selectable ones
@@ -1050,8 +1048,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
         obj.D = D;
         obj.col0 = last + 1;
         obj.z = 0.0;
-        const double* tab = Q + (size_t)(last + 1 - D) * PG;   // column q = column last+1+q
-        const int verdict = leaf_verdict<KD, PG, false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
+        const double* tab = Q + (size_t)(last + 1 - D) * PGT;   // column q = column last+1+q
+        const int verdict = leaf_verdict<KD, PGT, false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
         // (listed subsets are feasible by construction; a verdict mismatch would be a bug and shows
         // up as -inf here)
         const double score = verdict == 0 ? (d.maximize ? obj.z : -obj.z) : -INFINITY;
@@ -1067,8 +1065,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
 
 void lp_enum_queue_record_eval(lp_enum_problem* p, const double* roots) {
     lp_context* ctx = p->ctx;
-    hipLaunchKernelGGL(k_enum_eval_records, (unsigned)ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev,
-                       p->prefix, roots, p->prefix.scores);
+    if (p->dev.m > PG)
+        hipLaunchKernelGGL(k_enum_eval_records<32>, (unsigned)ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev,
+                           p->prefix, roots, p->prefix.scores);
+    else
+        hipLaunchKernelGGL(k_enum_eval_records<PG>, (unsigned)ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev,
+                           p->prefix, roots, p->prefix.scores);
 }
 
 // Second phase of the shared-prefix pass over the records of the last breadth-first level
@@ -1076,11 +1078,10 @@ void lp_enum_queue_record_eval(lp_enum_problem* p, const double* roots) {
 // regular kernel pivots once more itself, the thin kernel takes the small tails) or, for m = 6, the
 // root record.  `bound6` bounds the number of depth m-6 nodes (sizes the item table).
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
-                          uint64_t bound6, uint64_t begin, uint64_t end) {
+                          int shape, uint64_t begin, uint64_t end) {
     lp_context* ctx = p->ctx;
     PrefixDev& pd = p->prefix;
     const int n = p->dev.n, m = p->dev.m;
-    const uint64_t total = lp_host_binom(n, m);
     auto ensure = [&](int4*& items, int& cap, uint64_t want) -> int {
         if ((uint64_t)cap >= want) return LP_OPTIMAL;
         lp_pool_release(ctx, items, sizeof(int4) * (size_t)cap);
@@ -1091,6 +1092,24 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         cap = (int)std::min<uint64_t>(got / sizeof(int4), 0x7FFFFFFFULL);
         return LP_OPTIMAL;
     };
+    const bool general = shape != 1 || (fused && getenv("LP_ENUM_GENERIC"));   // (env: A/B on a tuned shape)
+    if (general) {
+        // one item per started run of kGenChunk subsets of a record
+        int rc = ensure(pd.items, pd.item_cap, (end - begin) / kGenChunk + (uint64_t)bound + 1024);
+        if (rc) return rc;
+        const unsigned long long b = begin, e = end;
+        const unsigned grid_items = (unsigned)lp_ceil_div(bound, 256), grid = (unsigned)ctx->num_cus * 8;
+        if (shape == 3) {
+            hipLaunchKernelGGL(k_enum_generic_items<32>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
+            hipLaunchKernelGGL(k_enum_generic_leaves<32>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
+        } else {
+            hipLaunchKernelGGL(k_enum_generic_items<PG>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
+            hipLaunchKernelGGL(k_enum_generic_leaves<PG>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
+        }
+        return LP_OPTIMAL;
+    }
+    const uint64_t total = lp_host_binom(n, m);
+    const uint64_t bound6 = lp_host_binom(n - m + level + 1, level + 1);   // depth m-6 nodes (sizes the item table)
     int rc = ensure(pd.items, pd.item_cap, bound6 + total / kChunk + 1024);
     if (rc) return rc;
     if (fused) {
@@ -1102,11 +1121,7 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     // persistent waves (items are dealt dynamically): as many blocks as are resident
     const int grid6 = ctx->num_cus * 3;
     const unsigned long long b = begin, e = end;
-    if (fused && getenv("LP_ENUM_GENERIC")) {   // (A/B: the general leaf kernel on a shape the tuned ones take)
-        hipLaunchKernelGGL(k_enum_generic_items<PG>, lp_ceil_div(bound, 256), 256, 0, ctx->stream, p->dev, pd, roots,
-                           level, bound, b, e);
-        hipLaunchKernelGGL(k_enum_generic_leaves<PG>, ctx->num_cus * 8, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
-    } else if (fused) {
+    if (fused) {
         // The three leaf kernels are independent of each other (own item table / work cursor, results
         // through atomics), and the thin kernel does not even need the item tables: they run on three
         // streams, so that the thin kernel overlaps the item builder and every kernel's tail (persistent

@@ -36,6 +36,7 @@ constexpr int kExpandParents = 64;  // parents per block of k_enum_expand (one s
 // ---------------------------------------------------------------------------
 // phase 1: expand level t -> t+1 (records in HBM)
 // ---------------------------------------------------------------------------
+template <int PGT, int NMXT>
 __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, int t,
                                                      const double* __restrict__ src, int src_cap,
                                                      double* __restrict__ dst, int dst_cap, int ppw,
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     __shared__ int s_base[kExpandParents];
     const int m = d.m, n = d.n;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, gl = lane & (PG - 1), g = lane >> 4, gbase = lane & ~(PG - 1);
+    constexpr int GW = 64 / PGT;   // groups (children in flight) per wave
+    using Meta = NodeMetaT<PGT>;
+    const int lane = tid & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
     // the level's record count lives on the device (level_counts[t]): the host queues all levels
     // without synchronising, with grids sized for an upper bound
     const int nsrc = min(pd.level_counts[t], src_cap);  // (an overflowed level is reported by the host)
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         const int node = first + tid;
         int nch = 0;
         if (tid < 4 * ppw && node < nsrc) {
-            const NodeMeta* q = reinterpret_cast<const NodeMeta*>(src + (size_t)node * rec_doubles(n, t) +
-                                                                  (size_t)PG * (n - t + 1));
+            const Meta* q = reinterpret_cast<const Meta*>(src + (size_t)node * rec_doubles_g<PGT>(n, t) +
+                                                                  (size_t)PGT * (n - t + 1));
             const int last = q->last_col;
             if (last != kHole) {
                 unsigned long long rb = q->rank_base;
@@ -93,15 +96,15 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int local = (tid >> 6) * ppw + it;
     const int node = first + local;
     if (node >= nsrc) break;
-    const double* P = src + (size_t)node * rec_doubles(n, t);
-    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
+    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t);
+    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)PGT * (n - t + 1));
     if (pm.last_col == kHole) continue;
     // ---- the children, one per lane: subset counts, rank bases (exclusive scan), range overlap
     const int a_l = pm.last_col + 1 + lane;
     const unsigned long long cnt_l = (a_l <= lim) ? binom(d, n - 1 - a_l, m - t - 1) : 0ULL;
     unsigned long long incl = cnt_l;
 #pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {   // at most NMX + 1 = 17 children
+    for (int off = 1; off < (NMXT > 16 ? 64 : 32); off <<= 1) {   // at most NMXT + 1 children
         const unsigned long long o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     if (nchild == 0) continue;
     const int wbase = s_base[local];
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-    const double prhs = P[(size_t)(n - t) * PG + gl];
+    const double prhs = P[(size_t)(n - t) * PGT + gl];
     unsigned long long sing = 0ULL;
-    for (int k0 = 0; k0 < nchild; k0 += 4) {
+    for (int k0 = 0; k0 < nchild; k0 += GW) {
         const int k = k0 + g;                  // this group's child (k-th valid one)
         const bool active = k < nchild;        // whole groups are active or not
         unsigned long long vm = vmask;
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             if (gl == 0) atomicExch(pd.overflow, 1);
             continue;
         }
-        double* C = dst + (size_t)myslot * rec_doubles(n, t + 1);
-        NodeMeta* cmeta = reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t));
-        const double w = P[(size_t)(a - t) * PG + gl];
+        double* C = dst + (size_t)myslot * rec_doubles_g<PGT>(n, t + 1);
+        Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)PGT * (n - t));
+        const double w = P[(size_t)(a - t) * PGT + gl];
         double big;
-        const int p = pick_pivot_row(w, prow_used, gbase, big);
+        const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
         const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
         if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
             sing += ov;  // the whole subtree is singular: leave a hole
@@ -151,23 +154,23 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         for (int c0 = a + 1; c0 < n; c0 += 6) {
             double own[6];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) own[u] = (c0 + u < n) ? P[(size_t)(c0 + u - t) * PG + gl] : 0.0;
+            for (int u = 0; u < 6; ++u) own[u] = (c0 + u < n) ? P[(size_t)(c0 + u - t) * PGT + gl] : 0.0;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const double pc = bcast16(own[u], addr);
-                if (c0 + u < n) C[(size_t)(c0 + u - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own[u]);
+                if (c0 + u < n) C[(size_t)(c0 + u - t - 1) * PGT + gl] = fma(lx, pc, isp ? -0.0 : own[u]);
             }
         }
         const double pr = bcast16(prhs, addr);
-        C[(size_t)(n - t - 1) * PG + gl] = fma(lx, pr, isp ? -0.0 : prhs);
+        C[(size_t)(n - t - 1) * PGT + gl] = fma(lx, pr, isp ? -0.0 : prhs);
         if (gl == 0) {
-            NodeMeta cm;
+            Meta cm;
             cm.rank_base = rb_child;
             cm.minp = minp;
             cm.maxp = maxp;
             cm.last_col = a;
             cm.used_mask = pm.used_mask | (1u << p);
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < PGT; ++q) {
                 cm.prow[q] = q == t ? (unsigned char)p : pm.prow[q];
                 cm.pcol[q] = q == t ? (unsigned char)a : pm.pcol[q];
             }
@@ -182,19 +185,22 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
 // one WAVE per (parent, child) — lane = (row, column quarter) — with all of the child's columns
 // in flight at once.  A lone 16-lane group pivoting up to n-m+1 children one after the other, four
 // dependent HBM round trips per child, takes ~60 us per level: most of a small shard's run time.
+template <int PGT, int NMXT>
 __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev pd, int t,
                                                             const double* __restrict__ src, int src_cap,
                                                             double* __restrict__ dst, int dst_cap,
                                                             unsigned long long begin,
                                                             unsigned long long end) {
     const int m = d.m, n = d.n, S = n - m + 1;   // S = most children a node can have
-    const int lane = threadIdx.x & 63, gl = lane & (PG - 1), g = lane >> 4, gbase = lane & ~(PG - 1);
+    constexpr int GW = 64 / PGT;
+    using Meta = NodeMetaT<PGT>;
+    const int lane = threadIdx.x & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
     const int wid = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int node = wid / S, j = wid - node * S;
     const int nsrc = min(pd.level_counts[t], src_cap);
     if (node >= nsrc) return;
-    const double* P = src + (size_t)node * rec_doubles(n, t);
-    const NodeMeta pm = *reinterpret_cast<const NodeMeta*>(P + (size_t)PG * (n - t + 1));
+    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t);
+    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)PGT * (n - t + 1));
     const int a = pm.last_col + 1 + j;
     if (pm.last_col == kHole || a > n - m + t) return;
     unsigned long long rb = pm.rank_base;
@@ -208,20 +214,20 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
         if (lane == 0) atomicExch(pd.overflow, 1);
         return;
     }
-    double* C = dst + (size_t)slot * rec_doubles(n, t + 1);
-    NodeMeta* cmeta = reinterpret_cast<NodeMeta*>(C + (size_t)PG * (n - t));
+    double* C = dst + (size_t)slot * rec_doubles_g<PGT>(n, t + 1);
+    Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)PGT * (n - t));
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-    const double w = P[(size_t)(a - t) * PG + gl];
+    const double w = P[(size_t)(a - t) * PGT + gl];
     // this group's columns (a+1+g, a+5+g, ...; column n = the rhs): all loads issued before use
-    constexpr int NC = (PG + NMX + 1 + 3) / 4;   // n <= 32 on this path: at most 33 columns
+    constexpr int NC = (PGT + NMXT + 1 + GW - 1) / GW;   // n <= PGT + NMXT: at most that many columns + rhs
     double own[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-        const int c = a + 1 + g + 4 * q;
-        own[q] = (c <= n) ? P[(size_t)(c - t) * PG + gl] : 0.0;
+        const int c = a + 1 + g + GW * q;
+        own[q] = (c <= n) ? P[(size_t)(c - t) * PGT + gl] : 0.0;
     }
     double big;
-    const int p = pick_pivot_row(w, prow_used, gbase, big);
+    const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
     const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
     if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
         if (lane == 0) {
@@ -236,18 +242,18 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
     const double lx = isp ? inv : -(w * inv);
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-        const int c = a + 1 + g + 4 * q;
+        const int c = a + 1 + g + GW * q;
         const double pc = bcast16(own[q], addr);
-        if (c <= n) C[(size_t)(c - t - 1) * PG + gl] = fma(lx, pc, isp ? -0.0 : own[q]);
+        if (c <= n) C[(size_t)(c - t - 1) * PGT + gl] = fma(lx, pc, isp ? -0.0 : own[q]);
     }
     if (lane == 0) {
-        NodeMeta cm;
+        Meta cm;
         cm.rank_base = rb;
         cm.minp = minp;
         cm.maxp = maxp;
         cm.last_col = a;
         cm.used_mask = pm.used_mask | (1u << p);
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < PGT; ++k) {
             cm.prow[k] = k == t ? (unsigned char)p : pm.prow[k];
             cm.pcol[k] = k == t ? (unsigned char)a : pm.pcol[k];
         }
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
 // root record (depth 0): the original [A | b]
 // (also resets every counter of the pass: one launch instead of two copies and four memsets,
 // each of which costs a 10-30 us enqueue gap at the start of a small rank range)
+template <int PGT>
 __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
     const int gl = threadIdx.x;
     if (gl < 32) pd.level_counts[gl] = gl == 0 ? 1 : 0;
@@ -273,18 +280,18 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
         pd.root_cursor[0] = pd.root_cursor[1] = 0;
         pd.item_count[0] = pd.item_count[1] = 0;
     }
-    if (gl >= PG) return;
-    for (int c = 0; c < d.n; ++c) dst[(size_t)c * PG + gl] = gl < d.m ? d.A[gl * d.lda + c] : 0.0;
-    dst[(size_t)d.n * PG + gl] = gl < d.m ? d.b[gl] : 0.0;
+    if (gl >= PGT) return;
+    for (int c = 0; c < d.n; ++c) dst[(size_t)c * PGT + gl] = gl < d.m ? d.A[gl * d.lda + c] : 0.0;
+    dst[(size_t)d.n * PGT + gl] = gl < d.m ? d.b[gl] : 0.0;
     if (gl == 0) {
-        NodeMeta cm;
+        NodeMetaT<PGT> cm;
         cm.rank_base = 0ULL;
         cm.minp = INFINITY;
         cm.maxp = 0.0;
         cm.last_col = -1;
         cm.used_mask = 0u;
-        for (int k = 0; k < 16; ++k) cm.prow[k] = cm.pcol[k] = 0;
-        *reinterpret_cast<NodeMeta*>(dst + (size_t)PG * (d.n + 1)) = cm;
+        for (int k = 0; k < PGT; ++k) cm.prow[k] = cm.pcol[k] = 0;
+        *reinterpret_cast<NodeMetaT<PGT>*>(dst + (size_t)PGT * (d.n + 1)) = cm;
     }
 }
 
@@ -294,7 +301,7 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
 // host driver
 // ---------------------------------------------------------------------------
 
-static size_t host_rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
+static size_t host_rec_doubles(int n, int t, int pg) { return (size_t)pg * (n - t + 1) + (pg == 32 ? 12 : 8); }
 
 // Number of depth-t tree nodes whose subtree meets the rank range [begin, end): the length-t
 // prefixes of the subsets begin .. end-1 are consecutive in the lexicographic order of the
@@ -320,10 +327,20 @@ static uint64_t host_level_nodes(int n, int m, uint64_t begin, uint64_t end, int
     return lp_host_prefix_rank(n, m, end - 1, t) - lp_host_prefix_rank(n, m, begin, t) + 1;
 }
 
-bool lp_enum_prefix_supported(const lp_enum_problem* p) {
-    const EnumDev& d = p->dev;
-    return d.m >= 6 && d.m <= PG && (d.n - d.m) <= NMX && (d.n - d.m) >= 2;  // m - 6 >= 0 levels
+// Shapes of the shared-prefix path:
+//   1  m in 6..16, n-m in 2..16: 16-row records, the tuned leaf kernels (subset tables, LDS slices)
+//   2  m in 7..16, n-m in 17..32: 16-row records, the general leaf kernel
+//   3  m in 17..32, n-m in 2..32: 32-row records, the general leaf kernel
+//   0  everything else (direct kernel)
+int lp_enum_prefix_shape(const lp_enum_problem* p) {
+    const int m = p->dev.m, nm = p->dev.n - p->dev.m;
+    if (nm < 2) return 0;
+    if (m >= 6 && m <= PG && nm <= NMX) return 1;
+    if (m >= 7 && m <= PG && nm <= 32) return 2;
+    if (m > PG && m <= 32 && nm <= 32) return 3;
+    return 0;
 }
+bool lp_enum_prefix_supported(const lp_enum_problem* p) { return lp_enum_prefix_shape(p) != 0; }
 
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
                          uint64_t counts[3], lp_enum_stats* stats) {
@@ -331,40 +348,67 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const EnumDev& d = p->dev;
     hipStream_t s = ctx->stream;
     const int m = d.m, n = d.n;
+    const int shape = lp_enum_prefix_shape(p);
+    const int pg = shape == 3 ? 32 : PG;
     // breadth-first to depth m-7 (m-6 for m = 6), then one lane per subset (enum_leaf.hip)
     // (the leaf kernel performs the pivot of depth m-6 itself, so the levels stop at depth m-7)
     const bool fused = m >= 7;
     const int D0 = fused ? m - 7 : m - 6;
     PrefixDev& pd = p->prefix;
-    // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0)
+    // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0) of the whole
+    // problem if that fits the budget (C(32,16): 6.4 GB), otherwise for as many records as fit; a
+    // range with more depth-D0 nodes than that is split by the caller (kEnumRangeTooWide)
     const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
-    const size_t need = (size_t)nodes_max * host_rec_doubles(n, D0) * sizeof(double);
-    const size_t need_prev = D0 >= 1 ? (size_t)lp_host_binom(n - m + D0 - 1, D0 - 1) * host_rec_doubles(n, D0 - 1) * sizeof(double)
-                                     : (size_t)host_rec_doubles(n, 0) * sizeof(double);
-    if (p->prefix_buf_bytes[0] < need) {
-        lp_pool_release(ctx, p->prefix_buf[0], p->prefix_buf_bytes[0]);
-        p->prefix_buf[0] = nullptr;
-        p->prefix_buf_bytes[0] = 0;
-        size_t free_b = 0, total_b = 0;
-        LP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-        if (need + need_prev > free_b / 10 * 9) {
-            // give back what the context's pool holds before giving up on this path
-            for (auto& b : ctx->pool) (void)hipFree(b.first);
-            ctx->pool.clear();
-            LP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t nodes_prev = D0 >= 1 ? lp_host_binom(n - m + D0 - 1, D0 - 1) : 1;
+    const size_t rec_bytes = host_rec_doubles(n, D0, pg) * sizeof(double);
+    const size_t rec_prev_bytes = host_rec_doubles(n, D0 >= 1 ? D0 - 1 : 0, pg) * sizeof(double);
+    uint64_t cap_budget0 = 0, cap_budget1 = 0;   // records the budget allows at depth D0 / D0-1
+    {
+        if (ctx->total_mem == 0) {
+            size_t free_b = 0;
+            LP_HIP(ctx, hipMemGetInfo(&free_b, &ctx->total_mem));
         }
-        if (need + need_prev > free_b / 10 * 9) return LP_ITER_LIMIT;  // caller falls back to direct
-        size_t got = 0;
-        LP_HIP(ctx, lp_pool_alloc(ctx, (void**)&p->prefix_buf[0], need, &got));
-        p->prefix_buf_bytes[0] = got;
+        size_t budget = std::min<size_t>(ctx->total_mem / 5 * 2, size_t(24) << 30);   // for both buffers together
+        if (const char* e = getenv("LP_ENUM_LEVEL_BUDGET_KB")) budget = (size_t)strtoull(e, nullptr, 10) << 10;   // (tests)
+        // level D0-1 holds at most as many records as level D0 (every record has a child or is a hole)
+        const uint64_t cap0 = std::max<uint64_t>(std::min<uint64_t>(nodes_max, budget / (rec_bytes + rec_prev_bytes)), 1);
+        const uint64_t cap1 = std::min<uint64_t>(nodes_prev, cap0);
+        cap_budget0 = cap0;
+        cap_budget1 = cap1;
+        const size_t want[2] = {(size_t)cap0 * rec_bytes, std::max<size_t>((size_t)cap1 * rec_prev_bytes, 4096)};
+        for (int k = 0; k < 2; ++k) {
+            if (p->prefix_buf_bytes[k] >= want[k]) continue;
+            lp_pool_release(ctx, p->prefix_buf[k], p->prefix_buf_bytes[k]);
+            p->prefix_buf[k] = nullptr;
+            p->prefix_buf_bytes[k] = 0;
+            size_t got = 0;
+            hipError_t e = lp_pool_alloc(ctx, (void**)&p->prefix_buf[k], want[k], &got);
+            if (e != hipSuccess) {
+                // give back what the context's pool holds before giving up on this path
+                (void)hipGetLastError();
+                for (auto& blk : ctx->pool) (void)hipFree(blk.first);
+                ctx->pool.clear();
+                e = lp_pool_alloc(ctx, (void**)&p->prefix_buf[k], want[k], &got);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return LP_ITER_LIMIT;   // caller falls back to the direct kernel
+            }
+            p->prefix_buf_bytes[k] = got;
+        }
     }
-    if (p->prefix_buf_bytes[1] < need_prev) {
-        lp_pool_release(ctx, p->prefix_buf[1], p->prefix_buf_bytes[1]);
-        p->prefix_buf[1] = nullptr;
-        p->prefix_buf_bytes[1] = 0;
-        size_t got = 0;
-        LP_HIP(ctx, lp_pool_alloc(ctx, (void**)&p->prefix_buf[1], need_prev, &got));
-        p->prefix_buf_bytes[1] = got;
+    {
+        // the range's own node counts (exact) against what the buffers hold
+        // (a kept buffer may be larger than this problem's budget share: the budget decides, so that the
+        // behaviour does not depend on what ran before)
+        const uint64_t have0 = std::min<uint64_t>(p->prefix_buf_bytes[0] / rec_bytes, cap_budget0);
+        const uint64_t have1 = std::min<uint64_t>(p->prefix_buf_bytes[1] / rec_prev_bytes, cap_budget1);
+        const uint64_t want0 = host_level_nodes(n, m, begin, end, D0);
+        const uint64_t want1 = D0 >= 1 ? host_level_nodes(n, m, begin, end, D0 - 1) : 1;
+        if (want0 > have0 || want1 > have1 || want0 > 0x7FFFFFFFULL) {
+            p->split_hint = std::max<uint64_t>(want0 / std::max<uint64_t>(have0, 1), want1 / std::max<uint64_t>(have1, 1)) + 1;
+            return kEnumRangeTooWide;
+        }
     }
     // depth-D0 records always end in buffer 0; levels alternate so that level D0 lands there
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
@@ -373,13 +417,16 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     // All levels and the leaf kernel are queued without a host round trip: every level's record
     // count stays on the device (level_counts[t]); grids are sized for the combinatorial upper
     // bound C(n-m+t, t) of the level (blocks beyond the actual count return at once).
-    hipLaunchKernelGGL(k_enum_root, 1, 64, 0, s, d, pd, p->prefix_buf[cur]);   // + all counters reset
+    if (pg == 32)
+        hipLaunchKernelGGL(k_enum_root<32>, 1, 64, 0, s, d, pd, p->prefix_buf[cur]);
+    else
+        hipLaunchKernelGGL(k_enum_root<PG>, 1, 64, 0, s, d, pd, p->prefix_buf[cur]);   // + all counters reset
     ++launches;
     int caps[32];
     caps[0] = 1;
     for (int t = 0; t < D0; ++t) {
         const int nxt = cur ^ 1;
-        const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1) * sizeof(double));
+        const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1, pg) * sizeof(double));
         const int cap = cap64 > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)cap64;
         caps[t + 1] = cap;
         // parents of this level inside the range (exact; the level's holes are among them)
@@ -389,20 +436,35 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         const int groups_per_block = 4 * ppw;
         // narrow levels: one wave per (parent, child)
         const uint64_t waves = bound * (uint64_t)(n - m + 1);
-        if (waves <= (uint64_t)ctx->num_cus * 128)
-            hipLaunchKernelGGL(k_enum_expand_narrow, (unsigned)lp_ceil_div<uint64_t>(waves, 4), 256, 0, s, d, pd, t,
-                               p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap,
-                               (unsigned long long)begin, (unsigned long long)end);
-        else
-            hipLaunchKernelGGL(k_enum_expand, (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block), 256, 0, s,
-                               d, pd, t, p->prefix_buf[cur], t == 0 ? 1 : caps[t], p->prefix_buf[nxt], cap, ppw,
-                               (unsigned long long)begin, (unsigned long long)end);
+        const bool narrow = waves <= (uint64_t)ctx->num_cus * 128;
+        const unsigned grid = narrow ? (unsigned)lp_ceil_div<uint64_t>(waves, 4)
+                                     : (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block);
+        const double* src = p->prefix_buf[cur];
+        double* dst = p->prefix_buf[nxt];
+        const int src_cap = t == 0 ? 1 : caps[t];
+        const unsigned long long b = begin, e = end;
+#define LP_EXPAND(PGT, NMXT)                                                                                   \
+    do {                                                                                                       \
+        if (narrow)                                                                                            \
+            hipLaunchKernelGGL((k_enum_expand_narrow<PGT, NMXT>), grid, 256, 0, s, d, pd, t, src, src_cap, dst, \
+                               cap, b, e);                                                                     \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_enum_expand<PGT, NMXT>), grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap,   \
+                               ppw, b, e);                                                                     \
+    } while (0)
+        if (shape == 1) LP_EXPAND(16, 16);
+        else if (shape == 2) LP_EXPAND(16, 32);
+        else LP_EXPAND(32, 32);
+#undef LP_EXPAND
         ++launches;
         cur = nxt;
     }
     const uint64_t root_bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, D0), 0x7FFFFFFFULL);
-    lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]), D0,
-                          fused, lp_host_binom(n - m + D0 + 1, D0 + 1), begin, end);
+    {
+        const int rc = lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]),
+                                             D0, fused, shape, begin, end);
+        if (rc) return rc;
+    }
     ++launches;
     LP_HIP(ctx, hipMemcpyAsync(p->h_level_counts, pd.level_counts, sizeof(int) * 32, hipMemcpyDeviceToHost, s));
     // objectives of the (few) feasible subsets by the direct solver, and the tie rule against this

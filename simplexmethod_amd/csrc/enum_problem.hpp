@@ -96,6 +96,7 @@ struct lp_enum_problem {
     bool list_valid = false;                   // the feasible list of the last prefix pass 1 is usable
     uint64_t list_begin = 0, list_end = 0, list_n = 0;
     int last_algo = 0;
+    uint64_t split_hint = 0;
     // A range whose feasible subsets do not fit the list (degenerate LPs: up to every non-singular
     // basis is feasible) is enumerated in sub-ranges, one list at a time; pass 2 re-runs only the
     // sub-ranges whose best score can hold the winner.
@@ -133,14 +134,19 @@ int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* record
 void lp_enum_queue_record_eval(lp_enum_problem* p, const double* records);
 
 // enum_leaf.hip: one lane per subset below the records of the last breadth-first level
+// (shape: lp_enum_prefix_shape — 1 = the tuned kernels, 2 / 3 = the general kernel on 16- / 32-row records)
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
-                          uint64_t bound6, uint64_t begin, uint64_t end);
+                          int shape, uint64_t begin, uint64_t end);
 
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
+int lp_enum_prefix_shape(const lp_enum_problem* p);
 // LP_ITER_LIMIT = "could not run here (memory / a level buffer too small), use the direct path";
 // kEnumListOverflow = the feasible list was too small: *h_list_count holds the number of feasible
 // subsets of the range, the caller splits the range (capi.hip: enum_prefix_chunked)
 constexpr int kEnumListOverflow = 1001;
+// kEnumRangeTooWide = the range has more depth m-7 nodes than the level buffers hold: the caller
+// splits it into about p->split_hint parts
+constexpr int kEnumRangeTooWide = 1002;
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
                          uint64_t counts[3], lp_enum_stats* stats);

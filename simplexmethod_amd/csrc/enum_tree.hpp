@@ -13,19 +13,27 @@ constexpr int NMX = 16;           // max n - m on this path
 constexpr int META = 8;           // doubles of metadata behind each node record
 constexpr int kHole = -2;         // NodeMeta::last_col of a slot whose subtree was pruned
 
-struct NodeMeta {  // 64 bytes, stored behind the columns of a record
+// PATH = 16 (records of at most 16 rows: 64 bytes) or 32 (up to 32 rows: 96 bytes)
+template <int PATH>
+struct NodeMetaT {  // stored behind the columns of a record
     unsigned long long rank_base;  // rank of the first subset below this node
     double minp, maxp;             // smallest / largest |pivot| so far
     int last_col;                  // last chosen column (-1 at the root)
     unsigned used_mask;            // bit i: row i already used as a pivot row
-    unsigned char prow[16];        // prow[k], pcol[k]: pivot row and chosen column of depth k < the node's
-    unsigned char pcol[16];        // depth (the objective of a listed subset is summed in this order)
+    unsigned char prow[PATH];      // prow[k], pcol[k]: pivot row and chosen column of depth k < the node's
+    unsigned char pcol[PATH];      // depth (the objective of a listed subset is summed in this order)
 };
+using NodeMeta = NodeMetaT<16>;
 static_assert(sizeof(NodeMeta) == META * 8, "NodeMeta must be 64 bytes");
+static_assert(sizeof(NodeMetaT<32>) == 96, "NodeMetaT<32> must be 96 bytes");
 
-// Record of a depth-t node: columns t .. n-1 (16 doubles each, column-major), then the rhs
-// column, then the NodeMeta.  Only columns > last_col are meaningful.
+// Record of a depth-t node: columns t .. n-1 (PGT doubles each, column-major), then the rhs
+// column, then the node's metadata.  Only columns > last_col are meaningful.
 __host__ __device__ inline size_t rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
+template <int PGT>
+__host__ __device__ inline size_t rec_doubles_g(int n, int t) {
+    return (size_t)PGT * (n - t + 1) + sizeof(NodeMetaT<PGT>) / 8;
+}
 
 __device__ __forceinline__ unsigned long long binom(const EnumDev& d, int nn, int kk) {
     if (kk < 0 || nn < kk || nn < 0) return 0ULL;
@@ -73,6 +81,16 @@ __device__ __forceinline__ int pick_pivot_row(double w, bool used, int gbase, do
     const double a = used ? -1.0 : fabs(w);
     big = row_max_f64(a);
     const unsigned long long hit = (__ballot(a == big && !used) >> gbase) & 0xFFFFULL;
+    return hit ? (int)__builtin_ctzll(hit) : 0;
+}
+// the same for groups of PGT = 16 or 32 lanes
+template <int PGT>
+__device__ __forceinline__ int pick_pivot_row_g(double w, bool used, int gbase, double& big) {
+    const double a = used ? -1.0 : fabs(w);
+    double v = row_max_f64(a);
+    if constexpr (PGT == 32) v = fmax(v, __shfl_xor(v, 16, 64));
+    big = v;
+    const unsigned long long hit = (__ballot(a == big && !used) >> gbase) & (PGT == 32 ? 0xFFFFFFFFULL : 0xFFFFULL);
     return hit ? (int)__builtin_ctzll(hit) : 0;
 }
 

@@ -17,6 +17,7 @@ struct lp_context {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int num_cus = 0;
+    size_t total_mem = 0;   // device memory (queried on first use)
     std::string last_error;
     // Large device buffers released by freed problems, kept for the next one (hipMalloc / hipFree of
     // the enumeration's multi-GB level buffers cost milliseconds: more than a small solve).

@@ -172,6 +172,60 @@ def test_prefix_matches_oracle(ctx, m, n, seed):
     p.free()
 
 
+# ---- wide shapes: 32-row records (m > 16) and more than 16 selectable columns (n - m > 16) run the
+# general leaf kernel over the same depth m-7 records
+
+WIDE_SHAPES = [(17, 23, 81), (18, 24, 82), (20, 25, 83), (8, 26, 84), (7, 30, 85), (9, 27, 86),
+               (24, 28, 87), (17, 20, 88), (7, 39, 89)]
+
+
+@pytest.mark.parametrize("m,n,seed", WIDE_SHAPES)
+def test_wide_prefix_matches_oracle(ctx, m, n, seed):
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    p = ctx.enum_problem(A, b, c, True)
+    # windows of the rank space against the oracle (the whole space when it is small)
+    windows = [(0, total)] if total <= 400_000 else [(0, 60_000), (total // 3, total // 3 + 60_000), (total - 60_000, total)]
+    for lo, hi in windows:
+        st, z, counts = o.enum_range(A, b, c, True, lo, hi)
+        rc, gz, gcounts, _ = p.range(lo, hi, capi.ENUM_PREFIX)
+        assert (rc, gz, gcounts) == (st, z, counts), (m, n, lo, hi)
+        if st == 0:
+            assert p.first_within(lo, hi, z) == o.enum_first_within(A, b, c, True, lo, hi, z)
+    # the whole space: shared-prefix path against the direct kernel (itself oracle-checked above and in
+    # test_direct_*), optimum, counts, tie rule and the vertex
+    rc, gz, gcounts, _ = p.range(0, total, capi.ENUM_PREFIX)
+    assert sum(gcounts) == total
+    k = p.first_within(0, total, gz) if rc == 0 else None
+    rc2, dz, dcounts, _ = p.range(0, total, capi.ENUM_DIRECT)
+    assert (rc2, dz, dcounts) == (rc, gz, gcounts)
+    if rc == 0:
+        assert p.first_within(0, total, dz) == k
+        v = p.vertex(k)
+        _, xB, zz = o.enum_subset(A, b, c, o.unrank(n, m, k))
+        assert v["obj"] == zz == gz and np.array_equal(v["x"][v["basis"]], xB)
+    p.free()
+
+
+def test_wide_range_is_split_when_the_level_buffers_are_small(ctx, monkeypatch):
+    """Large shapes have more depth m-7 nodes than memory holds (C(n-7, m-7) records): the range is then
+    enumerated in sub-ranges whose nodes fit, each with its own list, and pass 2 re-runs only the
+    sub-range that holds the winner.  Forced here with a 64 KB budget for the level buffers (8-13 records)."""
+    monkeypatch.setenv("LP_ENUM_LEVEL_BUDGET_KB", "64")
+    for m, n, seed in [(18, 24, 82), (8, 26, 84), (11, 21, 91)]:   # 32-row records, general kernel, tuned kernels
+        A, b, c, _ = lpcases.random_lp(seed, m, n)
+        total = o.binom(n, m)
+        lo, hi = 0, total
+        ref = o.enum_range(A, b, c, True, lo, hi)
+        p = ctx.enum_problem(A, b, c, True)
+        got = p.range(lo, hi, capi.ENUM_PREFIX)
+        assert got[:3] == ref, (m, n)
+        assert got[3].launches > 30          # several sub-ranges ran
+        assert p.first_within(lo, hi, ref[1]) == o.enum_first_within(A, b, c, True, lo, hi, ref[1])
+        assert p.first_within(lo, hi, ref[1], 1e-3) == o.enum_first_within(A, b, c, True, lo, hi, ref[1], 1e-3)
+        p.free()
+
+
 def test_prefix_shards_and_minimise(ctx):
     rng = np.random.default_rng(77)
     m, n = 7, 17
