@@ -277,6 +277,37 @@ def enum_inputs_leg(ctx, args):
     return out
 
 
+def enum_wide_leg(ctx):
+    """Shapes outside the tuned kernels' 16 x 16 box: 32-row records (m > 16) and more than 16 selectable
+    columns run the general leaf kernel over the same shared prefixes; the direct kernel (one m x m solve
+    per subset) timed beside it on the smaller two.  One step = pass 1 + tie rule, seed 5."""
+    from simplexmethod_amd import capi
+    out = []
+    for m, n, with_direct in [(18, 30, True), (12, 32, True), (16, 34, False)]:
+        A, b, c, _ = capi.gen_lp(5, m, n)
+        p = ctx.enum_problem(A, b, c, True)
+        row = {"shape": f"C({n},{m})", "subsets": p.total}
+        answers = {}
+        for name, algo in (("prefix", capi.ENUM_PREFIX), ("direct", capi.ENUM_DIRECT)):
+            if name == "direct" and not with_direct:
+                continue
+            best = 1e9
+            for _ in range(2 if name == "prefix" else 1):
+                t0 = time.perf_counter()
+                rc, z, counts, st = p.range(0, p.total, algo)
+                k = p.first_within(0, p.total, z) if rc == 0 else None
+                best = min(best, time.perf_counter() - t0)
+            answers[name] = (rc, z, counts, k)
+            row[f"{name}_ms"] = round(1e3 * best, 3)
+            row[f"{name}_subsets_per_s"] = round(p.total / best, 1)
+        if len(answers) == 2:
+            row["same_answers"] = answers["prefix"] == answers["direct"]
+        row["optimum"], row["rank"] = answers["prefix"][1], answers["prefix"][3]
+        p.free()
+        out.append(row)
+    return out
+
+
 def two_phase_leg(ctx, args):
     """a Symmetrical-style MIN problem (no starting basis) through
     lp_simplex_two_phase; host-buffer entry point, so the time includes both uploads."""
@@ -486,6 +517,7 @@ def main():
             line["rankj_update"] = rankj
     if rank == 0 and world == 1 and not args.no_batched:
         line["enum"]["other_inputs"] = enum_inputs_leg(ctx, args)
+        line["enum"]["wide_shapes"] = enum_wide_leg(ctx)
         line["enum"]["worst_case_subsets_per_s"] = min(r.get("first_call_subsets_per_s", r["subsets_per_s"])
                                                        for r in line["enum"]["other_inputs"])
     if rank == 0 and not args.no_batched:

@@ -212,7 +212,10 @@ enum {
     LP_ENUM_ALGO_AUTO = 0,
     LP_ENUM_ALGO_DIRECT = 1, /* one independent m x m solve per subset                   */
     LP_ENUM_ALGO_PREFIX = 2  /* shared-prefix elimination over the combination tree
-                                (bit-identical results, far fewer flops)                 */
+                                (bit-identical results, far fewer flops): 6 <= m <= 16 with
+                                2 <= n-m <= 16 on the tuned kernels, 7 <= m <= 32 with
+                                n-m <= 32 on the general one; AUTO takes it for ranges of
+                                2^20 subsets or more                                     */
 };
 
 typedef struct lp_enum_stats {

@@ -622,8 +622,8 @@ int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_ou
     const uint64_t total = lp_host_binom(n, m);
     if (total == 0) return LP_BAD_ARG;
     const int d0 = m - 7;
-    // (the cost model is the shared-prefix path's; shapes it does not take — m > 16, n - m > 16 or
-    // < 2, small trees — run the direct kernel, whose cost per subset is uniform)
+    // (the cost model is that of the tuned kernels' box; the general kernel's shapes — m > 16 or
+    // n - m > 16 — small trees and the direct kernel get equal-size cuts)
     const bool prefix_shape = m >= 7 && m <= 16 && n - m >= 2 && n - m <= 16;
     if (shards == 1 || !prefix_shape || total < (1ULL << 20)) {
         // (dist.py uses total * k // world here; same partition property, sizes differ by <= 1)

@@ -7,7 +7,8 @@
 //
 // The sorted m-subsets form a tree (depth t = t columns chosen).  A node carries the
 // partially eliminated tableau restricted to the columns still selectable, [W[:, c > last] | rhs]
-// (16 rows x <= n-t+1 columns), the used-row mask and min/max |pivot|.
+// (16 or 32 rows x <= n-t+1 columns), the used-row mask, min/max |pivot| and the pivot row and
+// column of every depth so far.
 //
 //   phase 1  k_enum_expand / k_enum_expand_narrow (this file): levels 0 .. D0 breadth-first
 //            through HBM (D0 = m-7 for the default second phase).  One wave per parent, its
@@ -16,9 +17,12 @@
 //            Narrow levels: one wave per (parent, child).  Bandwidth-shaped (7 GB for C(32,16)).
 //   phase 2  the leaf kernels of enum_leaf.hip (one lane per subset from the depth
 //            m-7 records, with one or two more pivots done by the wave in LDS).
-//   Feasible subsets are rare; their ranks are appended to a list and their objectives are
-//   evaluated afterwards by the direct solver (enum_direct.hip: k_enum_eval_list), which
-//   also serves pass 2 (tie rule) without a second enumeration.
+//   Feasible subsets are rare; each is appended to a list as (rank, record index) and its objective
+//   is evaluated afterwards from that record (enum_leaf.hip: k_enum_eval_records; m = 6:
+//   enum_direct.hip: k_enum_eval_list); the scored list also serves pass 2 (tie rule) without a
+//   second enumeration.
+//   Records have 16 rows (m <= 16) or 32 (m <= 32): the kernels below are templates over the group
+//   width PGT and the column bound NMXT; <16, 16> is the tuned shape of C(32,16).
 //
 // Singular prefixes prune their whole subtree (min|piv| only falls, max|piv| only grows).
 #include <cfloat>

@@ -64,8 +64,8 @@ def balanced_shard_bounds(n, m, rank, world, record_cost=RECORD_COST):
     answer does not depend on where the cuts are (tie rule of SURVEY.md 8 row E1)."""
     total = _binom(n, m)
     d0 = m - 7
-    # (the cost model is the shared-prefix path's; shapes it does not take run the direct kernel,
-    # whose cost per subset is uniform)
+    # (the cost model is that of the tuned kernels' box; the general kernel's shapes and the direct
+    # kernel get equal-size cuts)
     prefix_shape = 7 <= m <= 16 and 2 <= n - m <= 16
     if world <= 1 or not prefix_shape or total < (1 << 20):
         return shard_bounds(total, rank, world)
