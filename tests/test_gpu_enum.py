@@ -363,6 +363,40 @@ def test_prefix_rejects_unsupported_shapes(ctx):
     p.free()
 
 
+@pytest.mark.parametrize("m,n", [(18, 30), (12, 32), (20, 30)])
+def test_wide_full_size_properties(ctx, m, n):
+    """Wide shapes at sizes the oracle cannot walk (86 M, 226 M and 30 M subsets): counts add up to C(n,m);
+    the optimum is the simplex optimum (a different algorithm on the same GPU); uneven shards compose to
+    the whole; the sharded entry point gives the same winner; the oracle agrees on a window around the
+    optimum."""
+    A, b, c, basis = lpcases.random_lp(3, m, n)
+    p = ctx.enum_problem(A, b, c, True)
+    total = p.total
+    rc, z, counts, _ = p.range(0, total)
+    assert rc == 0 and sum(counts) == total and counts[0] > 0
+    k = p.first_within(0, total, z)
+    v = p.vertex(k, n - m)
+    assert v["obj"] == z
+    s = ctx.simplex_solve(A, b, c, basis, True, n - m)
+    assert s["status"] == 0 and abs(s["obj"] - z) <= 1e-10 * abs(z)
+    np.testing.assert_allclose(v["x"], s["x"], rtol=0, atol=1e-9)
+    cuts = [0, total // 11, total // 3 + 7, total - total // 5, total]
+    acc, bests, firsts = np.zeros(3, dtype=np.int64), [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r1, zz, cc, _ = p.range(lo, hi)
+        acc += cc
+        bests.append(zz if r1 == 0 else -np.inf)
+        firsts.append(p.first_within(lo, hi, z) if r1 == 0 and zz >= z - 1e-9 else 2 ** 64 - 1)
+    assert acc.tolist() == counts and max(bests) == z and min(firsts) == k
+    g = p.solve_sharded(None, n - m)
+    assert g["rank"] == k and g["obj"] == z and g["counts"] == counts
+    lo = max(0, k - 20_000)
+    hi = min(total, k + 20_000)
+    ref = o.enum_range(A, b, c, True, lo, hi)
+    assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref and ref[1] == z
+    p.free()
+
+
 # ---- BASELINE.json's full sizes: size-independent properties -----------------------------------
 
 @pytest.mark.parametrize("m,n", [(14, 28), (16, 32)])   # configs[2], configs[3]
