@@ -894,12 +894,20 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
 
 template <int PGT>
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
-                                                                       const double* __restrict__ roots) {
+                                                                       const double* __restrict__ roots,
+                                                                       unsigned long long range_subsets) {
     constexpr int KD = 7;
+    constexpr int TSG = PGT + 1;                 // LDS column stride (odd: rows of different columns, different banks)
+    constexpr int GCOLS = NMXW + KD + 1;         // <= 39 selectable columns + rhs
     __shared__ unsigned int s_bin[(NMXW + KD + 2) * (KD + 1)];   // C(r, k), r <= NMXW + KD + 1, k <= KD
     __shared__ unsigned long long s_cnt[3];
+    // the item's record, one private slice per wave, rows PERMUTED: the 7 rows the prefix has not used
+    // first (ascending), then the used ones — leaf_verdict<PERM> then reads every row at a
+    // compile-time offset (no per-lane gathers from HBM/L1: those, ~100 per subset at a quarter of
+    // the LDS rate, bounded the first version of this kernel at 14 G subsets/s on C(32,16))
+    __shared__ double s_rec[LEAF_WAVES][GCOLS * TSG];
     const int m = d.m, n = d.n, D = m - KD;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMXW + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_bin[k] = (unsigned int)d.binom[r * kBinomK + kk];
@@ -908,28 +916,53 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
     __syncthreads();
     const int nitems = min(pd.item_count[0], pd.item_cap);
     unsigned int cnt[3] = {0u, 0u, 0u};
+    double* tab = s_rec[wave];
+    int staged = -1;   // record in this wave's slice
+    const int U[KD] = {0, 1, 2, 3, 4, 5, 6};   // unused by leaf_verdict<PERM>
+    // Items are dealt in runs (a returning atomic on one word costs ~11 ns chip-wide: at one draw per
+    // item, the 1.4 M mostly tiny items of C(30,18) took 15.6 ms whatever the lanes did): a static first
+    // deal, then runs that shrink with what is left (as k_enum_leaves); a run holds ~1024 subsets on
+    // average at most (16 items of tiny records, one full item), so that runs do not become the tail
+    const int kMaxRun = (int)max(1ULL, min(16ULL, 1024ULL * (unsigned long long)max(nitems, 1) / max(range_subsets, 1ULL)));
+    const int nwaves = (int)gridDim.x * LEAF_WAVES;
+    const int k0 = max(1, min(kMaxRun, nitems / (nwaves * 4)));
+    const int dyn_base = nwaves * k0;
+    int draw_next = ((int)blockIdx.x * LEAF_WAVES + wave) * k0, draw_end = draw_next + k0;
+    int seen = dyn_base;
     for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(&pd.root_cursor[0], 1);
-        item = __builtin_amdgcn_readfirstlane(item);
+        if (draw_next == draw_end) {
+            if (draw_end >= nitems) break;
+            const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
+            int v = 0;
+            if (lane == 0) v = atomicAdd(&pd.root_cursor[0], k);
+            draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            draw_end = draw_next + k;
+            seen = draw_end;
+        }
+        const int item = draw_next++;
         if (item >= nitems) break;
         const int4 it = pd.items[item];
-        const int rec = it.x;
+        const int rec = __builtin_amdgcn_readfirstlane(it.x);
         const double* Q = roots + (size_t)rec * rec_doubles_g<PGT>(n, D);
         const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)PGT * (n - D + 1));
-        const int last = pm->last_col;
+        const int last = __builtin_amdgcn_readfirstlane(pm->last_col);
         const int R = n - 1 - last;
-        const unsigned umask = pm->used_mask;
+        const unsigned umask = __builtin_amdgcn_readfirstlane(pm->used_mask);
         const unsigned long long rb = pm->rank_base;
         const double minp0 = pm->minp, maxp0 = pm->maxp;
-        int U[KD];
-        unsigned free_rows = ~umask & (m >= 32 ? ~0u : ((1u << m) - 1u));
-#pragma unroll
-        for (int r = 0; r < KD; ++r) {
-            U[r] = free_rows ? __builtin_ctz(free_rows) : 0;
-            free_rows &= free_rows - 1u;
+        if (rec != staged) {
+            // columns last+1 .. n-1 and the rhs, PGT rows each; a lane's row is the same in every round
+            const int row = lane & (PGT - 1);
+            const unsigned all = m >= 32 ? ~0u : ((1u << m) - 1u), below = (1u << row) - 1u, freem = ~umask & all;
+            const int pos = (row >= m) ? row
+                            : ((freem >> row) & 1u) ? __builtin_popcount(freem & below)
+                                                    : __builtin_popcount(freem) + __builtin_popcount(umask & all & below);
+            const double* src = Q + (size_t)(last + 1 - D) * PGT;
+            __builtin_amdgcn_wave_barrier();   // (the previous item's reads of the slice are done)
+            for (int k = lane; k < (R + 1) * PGT; k += 64) tab[(k / PGT) * TSG + pos] = src[k];
+            __builtin_amdgcn_wave_barrier();
+            staged = rec;
         }
-        const double* tab = Q + (size_t)(last + 1 - D) * PGT;   // column q = column last+1+q
         // this lane's share: K consecutive subsets from `mine`
         const unsigned int total = (unsigned int)it.z;
         const unsigned int K = (total + 63u) / 64u;
@@ -951,7 +984,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         }
         for (unsigned int k = 0; k < K; ++k) {
             if (k < have) {
-                const int verdict = leaf_verdict<KD, PGT, false>(tab, c, R, U, umask, minp0, maxp0, m);
+                const int verdict = leaf_verdict<KD, TSG, true>(tab, c, R, U, 0u, minp0, maxp0, m);
                 if (verdict == 0) {
                     const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
                     if (at < pd.list_cap) {
@@ -1101,10 +1134,10 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         const unsigned grid_items = (unsigned)lp_ceil_div(bound, 256), grid = (unsigned)ctx->num_cus * 8;
         if (shape == 3) {
             hipLaunchKernelGGL(k_enum_generic_items<32>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
-            hipLaunchKernelGGL(k_enum_generic_leaves<32>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
+            hipLaunchKernelGGL(k_enum_generic_leaves<32>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, e - b);
         } else {
             hipLaunchKernelGGL(k_enum_generic_items<PG>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
-            hipLaunchKernelGGL(k_enum_generic_leaves<PG>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots);
+            hipLaunchKernelGGL(k_enum_generic_leaves<PG>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, e - b);
         }
         return LP_OPTIMAL;
     }
