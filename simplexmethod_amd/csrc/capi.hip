@@ -688,6 +688,7 @@ static void enum_destroy(lp_enum_problem* p) {
     (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor);
     enum_list_release(p);
+    lp_pool_release(p->ctx, p->prefix.dense_scores, sizeof(double) * p->prefix.dense_cap);
     (void)hipFree(p->prefix.list_count);
     lp_pool_release(p->ctx, p->prefix.items, sizeof(int4) * (size_t)p->prefix.item_cap);
     lp_pool_release(p->ctx, p->prefix.items2, sizeof(int4) * (size_t)p->prefix.item_cap2);
@@ -753,6 +754,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         p->ctx = ctx;
     } else {   // forget what the previous problem left behind
         p->list_valid = p->spec_valid = p->pchunks_valid = false;
+        p->dense_active = p->dense_hint = false;
         p->pchunks.clear();
         p->shard_rank = p->shard_world = -1;
         p->last_begin = p->last_end = p->last_per_chunk = 0;
@@ -894,16 +896,31 @@ static bool enum_list_grow(lp_enum_problem* p, uint64_t nfeas) {
 // the memory, and the pass runs once more.
 static int enum_prefix_pass(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score, uint64_t counts[3],
                             lp_enum_stats* stats) {
-    int rc = lp_enum_prefix_range(p, begin, end, score, counts, stats);
-    if (rc == kEnumListOverflow && enum_list_grow(p, *p->h_list_count)) {
+    const bool pinned = getenv("LP_ENUM_LIST_CAP") != nullptr;   // tests pin the list to exercise the sub-range path
+    const bool may_dense = p->dev.m >= 7 && !pinned;
+    auto again = [&](bool dense) {   // one more pass, times and launches added up
         lp_enum_stats first{};
         if (stats) first = *stats;
-        rc = lp_enum_prefix_range(p, begin, end, score, counts, stats);
+        const int rc = lp_enum_prefix_range(p, begin, end, score, counts, stats, dense);
         if (stats) {
             stats->kernel_ms += first.kernel_ms;
             stats->launches += first.launches;
         }
+        return rc;
+    };
+    int rc = lp_enum_prefix_range(p, begin, end, score, counts, stats, p->dense_hint && may_dense);
+    if (p->dense_active) {
+        if (rc == LP_OPTIMAL && counts[0] * 8 < end - begin) p->dense_hint = false;   // not that degenerate after all
+        return rc;
     }
+    if (rc == kEnumListOverflow && may_dense && *p->h_list_count * 3 > end - begin) {
+        // more than a third of the range is feasible (the pass reported the count): the dense form —
+        // no list, every subset's score by rank — and later passes of this problem start there
+        p->dense_hint = true;
+        rc = again(true);
+        if (p->dense_active) return rc;
+    }
+    if (rc == kEnumListOverflow && enum_list_grow(p, *p->h_list_count)) rc = again(false);
     return rc;
 }
 

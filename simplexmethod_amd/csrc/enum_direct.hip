@@ -344,20 +344,22 @@ __global__ __launch_bounds__(256) void k_enum_eval_list(EnumDev d, const unsigne
     if (gl == 0 && best > -INFINITY) atomicMax(&d.result->best_key, lp_f64_key(best));
 }
 
+// list == null: the scores are indexed by rank - base (the dense form of a degenerate LP's pass)
 __global__ void k_enum_list_first(EnumDev d, const unsigned long long* list, unsigned long long count,
                                   const unsigned long long* count_ptr, unsigned long long cap,
-                                  const double* scores, double star, double tol) {
-    // count_ptr != null: queued behind k_enum_eval_list — list length and the best score (the
-    // reference value of the tie rule) are read on the device
-    if (count_ptr) {
-        count = *count_ptr < cap ? *count_ptr : cap;
-        star = lp_key_f64(d.result->best_key);
-    }
+                                  const double* scores, double star, double tol, unsigned long long base,
+                                  int star_on_device) {
+    // count_ptr != null: queued behind the evaluation kernel — the list length is read on the device;
+    // star_on_device: so is the best score (the reference value of the tie rule)
+    if (count_ptr) count = *count_ptr < cap ? *count_ptr : cap;
+    if (star_on_device) star = lp_key_f64(d.result->best_key);
     unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     unsigned long long first = ~0ULL;
-    for (; e < count; e += stride)
-        if (scores[e] >= star - tol && list[e] < first) first = list[e];
+    for (; e < count; e += stride) {
+        const unsigned long long rk = list ? list[e] : base + e;
+        if (scores[e] >= star - tol && rk < first) first = rk;
+    }
     if (first != ~0ULL) atomicMin(&d.result->first_rank, first);
 }
 
@@ -532,7 +534,18 @@ int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* record
         hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,
                            (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores);
     hipLaunchKernelGGL(k_enum_list_first, (unsigned)ctx->num_cus * 4, 256, 0, ctx->stream, d, pd.list, 0ULL,
-                       (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores, 0.0, tol);
+                       (const unsigned long long*)pd.list_count, (unsigned long long)pd.list_cap, pd.scores, 0.0, tol,
+                       0ULL, 1);
+    return LP_OPTIMAL;
+}
+
+// Dense form: tie rule over the rank-indexed scores of [begin, end), against the device's best score.
+int lp_enum_queue_dense_tail(lp_enum_problem* p, double tol, uint64_t begin, uint64_t end) {
+    lp_context* ctx = p->ctx;
+    hipLaunchKernelGGL(k_enum_list_first, (unsigned)ctx->num_cus * 4, 256, 0, ctx->stream, p->dev,
+                       (const unsigned long long*)nullptr, (unsigned long long)(end - begin),
+                       (const unsigned long long*)nullptr, 0ULL, p->prefix.dense_scores, 0.0, tol,
+                       (unsigned long long)begin, 1);
     return LP_OPTIMAL;
 }
 
@@ -542,10 +555,16 @@ int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64
     if (p->list_n == 0) return LP_OPTIMAL;
     int rc = reset_result(p);
     if (rc) return rc;
-    const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(p->list_n, 256), 1024);
-    hipLaunchKernelGGL(k_enum_list_first, grid, 256, 0, ctx->stream, p->dev, p->prefix.list,
-                       (unsigned long long)p->list_n, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores,
-                       score_star, tol);
+    const uint64_t entries = p->dense_active ? p->list_end - p->list_begin : p->list_n;
+    const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(entries, 256), 1024);
+    if (p->dense_active)
+        hipLaunchKernelGGL(k_enum_list_first, grid, 256, 0, ctx->stream, p->dev, (const unsigned long long*)nullptr,
+                           (unsigned long long)(p->list_end - p->list_begin), (const unsigned long long*)nullptr, 0ULL,
+                           p->prefix.dense_scores, score_star, tol, (unsigned long long)p->list_begin, 0);
+    else
+        hipLaunchKernelGGL(k_enum_list_first, grid, 256, 0, ctx->stream, p->dev, p->prefix.list,
+                           (unsigned long long)p->list_n, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores,
+                           score_star, tol, 0ULL, 0);
     rc = fetch_result(p);
     if (rc) return rc;
     *rank_out = p->h_result->first_rank;

@@ -64,6 +64,7 @@ struct LeafObj {
     const unsigned char* pcol;
     int D;                        // depth of the record
     int col0;                     // original column of tableau column 0
+    unsigned used;                // PERM: rows used by the prefix (row i sits at KD + #used rows below i)
     double z;
 };
 
@@ -257,7 +258,11 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     };
     if constexpr (OBJ) {
         double z = 0.0;
-        for (int k = 0; k < obj->D; ++k) z = fma(obj->cost[obj->pcol[k]], one_row(obj->prow[k], true), z);
+        for (int k = 0; k < obj->D; ++k) {
+            int i = obj->prow[k];
+            if constexpr (PERM) i = KD + __builtin_popcount(obj->used & ((1u << i) - 1u));
+            z = fma(obj->cost[obj->pcol[k]], one_row(i, true), z);
+        }
 #pragma unroll
         for (int r = 0; r < KD - 2; ++r) z = fma(obj->cost[obj->col0 + c[r]], xr[r], z);
         z = fma(obj->cost[obj->col0 + c[KD - 2]], xa, z);
@@ -892,10 +897,14 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
     }
 }
 
-template <int PGT>
+// DENSE (a degenerate LP: a large part of the range is feasible): no list — every subset is finished
+// without the early exit, its objective summed as the direct solver sums it, and its score (-inf if
+// not feasible) written to dense_scores[rank - begin]; the tie rule then runs over that array.
+template <int PGT, bool DENSE>
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
                                                                        const double* __restrict__ roots,
-                                                                       unsigned long long range_subsets) {
+                                                                       unsigned long long range_subsets,
+                                                                       unsigned long long begin) {
     constexpr int KD = 7;
     constexpr int TSG = PGT + 1;                 // LDS column stride (odd: rows of different columns, different banks)
     constexpr int GCOLS = NMXW + KD + 1;         // <= 39 selectable columns + rhs
@@ -906,6 +915,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
     // compile-time offset (no per-lane gathers from HBM/L1: those, ~100 per subset at a quarter of
     // the LDS rate, bounded the first version of this kernel at 14 G subsets/s on C(32,16))
     __shared__ double s_rec[LEAF_WAVES][GCOLS * TSG];
+    __shared__ double s_cost[DENSE ? kEnumMaxN : 1];
+    __shared__ unsigned long long s_best;
+    double best = -INFINITY;
     const int m = d.m, n = d.n, D = m - KD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMXW + KD + 2) * (KD + 1); k += LEAF_THREADS) {
@@ -913,6 +925,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         s_bin[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
+    if (DENSE && tid < d.n) s_cost[tid] = d.c[tid];
+    if (tid == 0) s_best = lp_f64_key(-INFINITY);
     __syncthreads();
     const int nitems = min(pd.item_count[0], pd.item_cap);
     unsigned int cnt[3] = {0u, 0u, 0u};
@@ -984,12 +998,28 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         }
         for (unsigned int k = 0; k < K; ++k) {
             if (k < have) {
-                const int verdict = leaf_verdict<KD, TSG, true>(tab, c, R, U, 0u, minp0, maxp0, m);
-                if (verdict == 0) {
-                    const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
-                    if (at < pd.list_cap) {
-                        pd.list[at] = rb + mine + k;
-                        pd.list_rec[at] = rec;
+                int verdict;
+                if constexpr (DENSE) {
+                    LeafObj obj;
+                    obj.cost = s_cost;
+                    obj.prow = pm->prow;
+                    obj.pcol = pm->pcol;
+                    obj.D = D;
+                    obj.col0 = last + 1;
+                    obj.used = umask;
+                    obj.z = 0.0;
+                    verdict = leaf_verdict<KD, TSG, true, true>(tab, c, R, U, 0u, minp0, maxp0, m, &obj);
+                    const double score = verdict == 0 ? (d.maximize ? obj.z : -obj.z) : -INFINITY;
+                    pd.dense_scores[rb + mine + k - begin] = score;
+                    best = fmax(best, score);
+                } else {
+                    verdict = leaf_verdict<KD, TSG, true>(tab, c, R, U, 0u, minp0, maxp0, m);
+                    if (verdict == 0) {
+                        const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                        if (at < pd.list_cap) {
+                            pd.list[at] = rb + mine + k;
+                            pd.list_rec[at] = rec;
+                        }
                     }
                 }
                 cnt[0] += verdict == 0;
@@ -1017,8 +1047,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
         if (lane == 0 && x) atomicAdd(&s_cnt[v], (unsigned long long)x);
     }
+    if (DENSE && best > -INFINITY) atomicMax(&s_best, lp_f64_key(best));
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
+    if (DENSE && tid == 0 && s_best != lp_f64_key(-INFINITY)) atomicMax(&d.result->best_key, s_best);
 }
 
 // Objectives of the listed (feasible) subsets from the depth m-7 records they were found under: one
@@ -1080,6 +1112,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
         obj.pcol = pm->pcol;
         obj.D = D;
         obj.col0 = last + 1;
+        obj.used = umask;
         obj.z = 0.0;
         const double* tab = Q + (size_t)(last + 1 - D) * PGT;   // column q = column last+1+q
         const int verdict = leaf_verdict<KD, PGT, false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
@@ -1111,7 +1144,7 @@ void lp_enum_queue_record_eval(lp_enum_problem* p, const double* roots) {
 // regular kernel pivots once more itself, the thin kernel takes the small tails) or, for m = 6, the
 // root record.  `bound6` bounds the number of depth m-6 nodes (sizes the item table).
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
-                          int shape, uint64_t begin, uint64_t end) {
+                          int shape, bool dense, uint64_t begin, uint64_t end) {
     lp_context* ctx = p->ctx;
     PrefixDev& pd = p->prefix;
     const int n = p->dev.n, m = p->dev.m;
@@ -1125,20 +1158,26 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         cap = (int)std::min<uint64_t>(got / sizeof(int4), 0x7FFFFFFFULL);
         return LP_OPTIMAL;
     };
-    const bool general = shape != 1 || (fused && getenv("LP_ENUM_GENERIC"));   // (env: A/B on a tuned shape)
+    const bool general = shape != 1 || dense || (fused && getenv("LP_ENUM_GENERIC"));   // (env: A/B on a tuned shape)
     if (general) {
         // one item per started run of kGenChunk subsets of a record
         int rc = ensure(pd.items, pd.item_cap, (end - begin) / kGenChunk + (uint64_t)bound + 1024);
         if (rc) return rc;
         const unsigned long long b = begin, e = end;
         const unsigned grid_items = (unsigned)lp_ceil_div(bound, 256), grid = (unsigned)ctx->num_cus * 8;
-        if (shape == 3) {
-            hipLaunchKernelGGL(k_enum_generic_items<32>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
-            hipLaunchKernelGGL(k_enum_generic_leaves<32>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, e - b);
-        } else {
-            hipLaunchKernelGGL(k_enum_generic_items<PG>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, b, e);
-            hipLaunchKernelGGL(k_enum_generic_leaves<PG>, grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, e - b);
-        }
+#define LP_GEN(PGT)                                                                                                      \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL(k_enum_generic_items<PGT>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, \
+                           b, e);                                                                                        \
+        if (dense)                                                                                                       \
+            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, true>), grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd,      \
+                               roots, e - b, b);                                                                         \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, false>), grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd,     \
+                               roots, e - b, b);                                                                         \
+    } while (0)
+        if (shape == 3) LP_GEN(32); else LP_GEN(PG);
+#undef LP_GEN
         return LP_OPTIMAL;
     }
     const uint64_t total = lp_host_binom(n, m);

@@ -347,7 +347,7 @@ int lp_enum_prefix_shape(const lp_enum_problem* p) {
 bool lp_enum_prefix_supported(const lp_enum_problem* p) { return lp_enum_prefix_shape(p) != 0; }
 
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
-                         uint64_t counts[3], lp_enum_stats* stats) {
+                         uint64_t counts[3], lp_enum_stats* stats, bool dense) {
     lp_context* ctx = p->ctx;
     const EnumDev& d = p->dev;
     hipStream_t s = ctx->stream;
@@ -359,6 +359,20 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const bool fused = m >= 7;
     const int D0 = fused ? m - 7 : m - 6;
     PrefixDev& pd = p->prefix;
+    p->dense_active = false;
+    if (dense && !fused) dense = false;
+    if (dense && pd.dense_cap < end - begin) {   // rank-indexed scores of the range (8 bytes per subset)
+        lp_pool_release(ctx, pd.dense_scores, sizeof(double) * pd.dense_cap);
+        pd.dense_scores = nullptr;
+        pd.dense_cap = 0;
+        size_t got = 0;
+        if (lp_pool_alloc(ctx, (void**)&pd.dense_scores, sizeof(double) * (end - begin), &got) == hipSuccess) {
+            pd.dense_cap = got / sizeof(double);
+        } else {
+            (void)hipGetLastError();
+            dense = false;   // no memory for it: the list form
+        }
+    }
     // ---- buffers: two ping-pong level arrays sized for the widest level (depth D0) of the whole
     // problem if that fits the budget (C(32,16): 6.4 GB), otherwise for as many records as fit; a
     // range with more depth-D0 nodes than that is split by the caller (kEnumRangeTooWide)
@@ -466,7 +480,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const uint64_t root_bound = std::min<uint64_t>(host_level_nodes(n, m, begin, end, D0), 0x7FFFFFFFULL);
     {
         const int rc = lp_enum_launch_leaves(p, p->prefix_buf[cur], (int)std::min<uint64_t>(root_bound, (uint64_t)caps[D0]),
-                                             D0, fused, shape, begin, end);
+                                             D0, fused, shape, dense, begin, end);
         if (rc) return rc;
     }
     ++launches;
@@ -475,7 +489,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     // range's own best score (what a sharded run asks next): queued behind the leaf kernels
     constexpr double kSpecTol = 1e-9;   // Solver::EPS, the tolerance dist.py / EnumerationSolver use
     p->spec_valid = false;
-    lp_enum_queue_list_tail(p, kSpecTol, fused ? p->prefix_buf[cur] : nullptr);
+    if (dense)
+        lp_enum_queue_dense_tail(p, kSpecTol, begin, end);
+    else
+        lp_enum_queue_list_tail(p, kSpecTol, fused ? p->prefix_buf[cur] : nullptr);
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -487,7 +504,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     if (*p->h_overflow != 0) return LP_ITER_LIMIT;  // fall back
     float ms = 0.f;
     LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    if (*p->h_list_count > pd.list_cap) {   // the caller grows the list or splits the range
+    if (!dense && *p->h_list_count > pd.list_cap) {   // the caller grows the list or splits the range
         if (stats) {
             stats->kernel_ms = ms;
             stats->subsets = end - begin;
@@ -495,7 +512,8 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
         }
         return kEnumListOverflow;
     }
-    const uint64_t nfeas = *p->h_list_count;
+    const uint64_t nfeas = dense ? p->h_result->counts[0] : *p->h_list_count;
+    p->dense_active = dense;
     double best = -INFINITY;
     if (nfeas) best = lp_key_f64(p->h_result->best_key);
     p->spec_valid = true;

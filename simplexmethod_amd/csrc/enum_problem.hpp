@@ -57,6 +57,8 @@ struct PrefixDev {
     unsigned long long* list_count;
     unsigned long long list_cap;
     double* scores;                   // objective score of each list entry (after evaluation)
+    double* dense_scores;             // dense form (degenerate LPs): score of every subset of the range, by
+    unsigned long long dense_cap;     // rank - begin (-inf: not feasible); no list
     int4* items;                      // leaf-kernel work items, table 0: (record, child column, first subset, rank offset)
     int4* items2;                     // table 1 (two-level kernel): (record, child | j2 << 8, first subset, rank offset)
     int* item_count;                  // [2]
@@ -97,6 +99,9 @@ struct lp_enum_problem {
     uint64_t list_begin = 0, list_end = 0, list_n = 0;
     int last_algo = 0;
     uint64_t split_hint = 0;
+    // dense form of a pass (enum_prefix.hip): chosen when a pass finds more than a third of its range
+    // feasible; dense_hint keeps later passes of this problem from listing first
+    bool dense_active = false, dense_hint = false;
     // A range whose feasible subsets do not fit the list (degenerate LPs: up to every non-singular
     // basis is feasible) is enumerated in sub-ranges, one list at a time; pass 2 re-runs only the
     // sub-ranges whose best score can hold the winner.
@@ -131,12 +136,14 @@ int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64
 // evaluation + tie rule against the list's own best, queued without a host round trip; records !=
 // null: the depth m-7 records of the pass (the entries are evaluated from them, enum_leaf.hip)
 int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* records);
+int lp_enum_queue_dense_tail(lp_enum_problem* p, double tol, uint64_t begin, uint64_t end);
 void lp_enum_queue_record_eval(lp_enum_problem* p, const double* records);
 
 // enum_leaf.hip: one lane per subset below the records of the last breadth-first level
 // (shape: lp_enum_prefix_shape — 1 = the tuned kernels, 2 / 3 = the general kernel on 16- / 32-row records)
+// dense: every subset's score goes to prefix.dense_scores[rank - begin] (general kernel), no list
 int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, int level, bool fused,
-                          int shape, uint64_t begin, uint64_t end);
+                          int shape, bool dense, uint64_t begin, uint64_t end);
 
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
@@ -149,4 +156,4 @@ constexpr int kEnumListOverflow = 1001;
 // splits it into about p->split_hint parts
 constexpr int kEnumRangeTooWide = 1002;
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
-                         uint64_t counts[3], lp_enum_stats* stats);
+                         uint64_t counts[3], lp_enum_stats* stats, bool dense = false);
