@@ -244,10 +244,10 @@ def enum_inputs_leg(ctx, args):
     """The enumeration's throughput depends on the data (wave-level early exit of infeasible
     subsets, number of feasible bases): the headline seed next to three more seeds and to the worst
     case for the feasible list, a fully degenerate LP (b = 0: every non-singular basis is feasible;
-    the first pass overflows the list and reports the count, the list is re-allocated to hold all
-    601 M entries, the pass runs once more and every entry's objective is evaluated from the record
-    it was found under).  One step = pass 1 + tie rule; the degenerate case is reported for its first
-    call (overflowing pass + 12 GB allocation + second pass) and for a repeat on the grown list."""
+    the first pass stops once its list is far over capacity and the range is redone in the dense form —
+    every subset's score by rank, no list).  One step = pass 1 + tie rule; the degenerate case is
+    reported for its first call (stopped listing pass + 4.8 GB allocation + dense pass) and for a
+    repeat (dense pass only)."""
     from simplexmethod_amd import capi
     m, n = args.enum_m, args.enum_n
     out = []

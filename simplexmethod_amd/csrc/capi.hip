@@ -892,8 +892,9 @@ static bool enum_list_grow(lp_enum_problem* p, uint64_t nfeas) {
 }
 
 // One shared-prefix pass over [begin, end).  A list that overflows (a degenerate LP: up to every
-// non-singular basis is feasible) is re-allocated for the count the pass reported, if the device has
-// the memory, and the pass runs once more.
+// non-singular basis is feasible) either gives way to the dense form (a large part of the range
+// feasible) or is re-allocated for the count the pass reported, if the device has the memory, and the
+// pass runs once more.
 static int enum_prefix_pass(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score, uint64_t counts[3],
                             lp_enum_stats* stats) {
     const bool pinned = getenv("LP_ENUM_LIST_CAP") != nullptr;   // tests pin the list to exercise the sub-range path
@@ -913,9 +914,11 @@ static int enum_prefix_pass(lp_enum_problem* p, uint64_t begin, uint64_t end, do
         if (rc == LP_OPTIMAL && counts[0] * 8 < end - begin) p->dense_hint = false;   // not that degenerate after all
         return rc;
     }
-    if (rc == kEnumListOverflow && may_dense && *p->h_list_count * 3 > end - begin) {
-        // more than a third of the range is feasible (the pass reported the count): the dense form —
-        // no list, every subset's score by rank — and later passes of this problem start there
+    if (rc == kEnumListOverflow && may_dense &&
+        (*p->h_list_count > p->prefix.list_abort || *p->h_list_count * 3 > end - begin)) {
+        // more than a third of the range is feasible (the pass reported the count), or the pass stopped
+        // early on a list 16x over capacity: the dense form — no list, every subset's score by rank —
+        // and later passes of this problem start there
         p->dense_hint = true;
         rc = again(true);
         if (p->dense_active) return rc;

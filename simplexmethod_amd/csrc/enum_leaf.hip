@@ -497,9 +497,15 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     auto draw = [&]() {
         if (draw_next == draw_end && draw_end < nitems) {
             const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
-            int v = 0;
-            if (lane == 0) v = atomicAdd(cursor, k);
+            int v = 0, over = 0;
+            if (lane == 0) {
+                v = atomicAdd(cursor, k);
+                // a list far beyond its capacity (a degenerate LP): the caller switches to the dense form
+                // whatever else this pass finds, so the waves stop drawing (the load rides with the atomic)
+                over = __hip_atomic_load(pd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pd.list_abort;
+            }
             draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            if (__builtin_amdgcn_readfirstlane(over)) draw_next = nitems;
             draw_end = draw_next + k;
             seen = draw_end;
         }
@@ -901,7 +907,7 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
 // without the early exit, its objective summed as the direct solver sums it, and its score (-inf if
 // not feasible) written to dense_scores[rank - begin]; the tie rule then runs over that array.
 template <int PGT, bool DENSE>
-__global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
+__global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
                                                                        const double* __restrict__ roots,
                                                                        unsigned long long range_subsets,
                                                                        unsigned long long begin) {
@@ -947,9 +953,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_generic_leaves(EnumDev d,
         if (draw_next == draw_end) {
             if (draw_end >= nitems) break;
             const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
-            int v = 0;
-            if (lane == 0) v = atomicAdd(&pd.root_cursor[0], k);
+            int v = 0, over = 0;
+            if (lane == 0) {
+                v = atomicAdd(&pd.root_cursor[0], k);
+                if (!DENSE)   // (a list far beyond its capacity: the caller switches to the dense form)
+                    over = __hip_atomic_load(pd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pd.list_abort;
+            }
             draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            if (__builtin_amdgcn_readfirstlane(over)) draw_next = nitems;
             draw_end = draw_next + k;
             seen = draw_end;
         }

@@ -361,6 +361,9 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     PrefixDev& pd = p->prefix;
     p->dense_active = false;
     if (dense && !fused) dense = false;
+    // a listing pass whose list is already 16x over capacity stops early: the caller goes dense on that
+    // count alone (LP_ENUM_LIST_CAP, the tests' pinned list, needs the exact count for its sub-ranges)
+    pd.list_abort = (fused && getenv("LP_ENUM_LIST_CAP") == nullptr) ? 16 * pd.list_cap : ~0ULL;
     if (dense && pd.dense_cap < end - begin) {   // rank-indexed scores of the range (8 bytes per subset)
         lp_pool_release(ctx, pd.dense_scores, sizeof(double) * pd.dense_cap);
         pd.dense_scores = nullptr;

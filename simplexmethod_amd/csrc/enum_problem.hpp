@@ -56,6 +56,7 @@ struct PrefixDev {
     int* list_rec;                    // record (last breadth-first level) each entry was found under
     unsigned long long* list_count;
     unsigned long long list_cap;
+    unsigned long long list_abort;    // leaf kernels stop drawing items once the list count exceeds this
     double* scores;                   // objective score of each list entry (after evaluation)
     double* dense_scores;             // dense form (degenerate LPs): score of every subset of the range, by
     unsigned long long dense_cap;     // rank - begin (-inf: not feasible); no list
