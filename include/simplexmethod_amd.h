@@ -213,9 +213,9 @@ enum {
     LP_ENUM_ALGO_DIRECT = 1, /* one independent m x m solve per subset                   */
     LP_ENUM_ALGO_PREFIX = 2  /* shared-prefix elimination over the combination tree
                                 (bit-identical results, far fewer flops): 6 <= m <= 16 with
-                                2 <= n-m <= 16 on the tuned kernels, 7 <= m <= 32 with
-                                n-m <= 32 on the general one; AUTO takes it for ranges of
-                                2^20 subsets or more                                     */
+                                2 <= n-m <= 16 on the tuned kernels; 7 <= m <= 16 with any
+                                n <= 64, or 17 <= m <= 32 with n-m <= 32, on the general one;
+                                AUTO takes it for ranges of 2^20 subsets or more         */
 };
 
 typedef struct lp_enum_stats {

@@ -1019,7 +1019,7 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
     switch (algo) {
         case LP_ENUM_ALGO_PREFIX:
             if (!lp_enum_prefix_supported(p))
-                LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 32 and 2 <= n-m <= 32 (m >= 7 beyond 16 x 16)");
+                LP_FAIL(ctx, LP_BAD_ARG, "shared-prefix enumeration needs 6 <= m <= 32 and n-m >= 2 (m >= 7 beyond 16 x 16; n-m <= 32 for m > 16)");
             rc = enum_prefix_pass(p, rank_begin, rank_end, &score, counts, stats_out);
             if (rc == kEnumRangeTooWide) {
                 // more depth m-7 nodes than the level buffers hold: sub-ranges, a quarter over the

@@ -868,7 +868,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
 // record where it lies (L1/L2: a record is at most 40 x 32 doubles) — leaf_verdict<7, PGT, false>,
 // the arithmetic of the thin kernel.
 constexpr int kGenChunk = 2048;   // subsets per item (32 per lane)
-constexpr int NMXW = 32;          // max n - m of the general path
+// max n - m of the general path: 32-row records (m > 16) with n <= 64 leave n - m <= 47 — the host
+// admits 32 there; 16-row records (7 <= m <= 16) go up to n - m = 57
+constexpr int nmxw(int pgt) { return pgt == 16 ? 57 : 32; }
 
 template <int PGT>
 __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev pd,
@@ -913,7 +915,8 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
                                                                        unsigned long long begin) {
     constexpr int KD = 7;
     constexpr int TSG = PGT + 1;                 // LDS column stride (odd: rows of different columns, different banks)
-    constexpr int GCOLS = NMXW + KD + 1;         // <= 39 selectable columns + rhs
+    constexpr int NMXW = nmxw(PGT);
+    constexpr int GCOLS = NMXW + KD + 1;         // <= n - m + 7 selectable columns + rhs
     __shared__ unsigned int s_bin[(NMXW + KD + 2) * (KD + 1)];   // C(r, k), r <= NMXW + KD + 1, k <= KD
     __shared__ unsigned long long s_cnt[3];
     // the item's record, one private slice per wave, rows PERMUTED: the 7 rows the prefix has not used
@@ -1075,6 +1078,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
                                                                      const double* __restrict__ roots,
                                                                      double* __restrict__ scores) {
     constexpr int KD = 7;
+    constexpr int NMXW = nmxw(PGT);
     __shared__ unsigned int s_bin[(NMXW + KD + 2) * (KD + 1)];   // C(r, k), r <= NMXW + KD + 1, k <= KD
     __shared__ double s_cost[kEnumMaxN];
     __shared__ unsigned long long s_best;

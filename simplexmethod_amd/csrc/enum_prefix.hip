@@ -333,14 +333,14 @@ static uint64_t host_level_nodes(int n, int m, uint64_t begin, uint64_t end, int
 
 // Shapes of the shared-prefix path:
 //   1  m in 6..16, n-m in 2..16: 16-row records, the tuned leaf kernels (subset tables, LDS slices)
-//   2  m in 7..16, n-m in 17..32: 16-row records, the general leaf kernel
+//   2  m in 7..16, n-m in 17..57 (n <= 64): 16-row records, the general leaf kernel
 //   3  m in 17..32, n-m in 2..32: 32-row records, the general leaf kernel
 //   0  everything else (direct kernel)
 int lp_enum_prefix_shape(const lp_enum_problem* p) {
     const int m = p->dev.m, nm = p->dev.n - p->dev.m;
     if (nm < 2) return 0;
     if (m >= 6 && m <= PG && nm <= NMX) return 1;
-    if (m >= 7 && m <= PG && nm <= 32) return 2;
+    if (m >= 7 && m <= PG && nm <= 57) return 2;
     if (m > PG && m <= 32 && nm <= 32) return 3;
     return 0;
 }
@@ -474,7 +474,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
                                ppw, b, e);                                                                     \
     } while (0)
         if (shape == 1) LP_EXPAND(16, 16);
-        else if (shape == 2) LP_EXPAND(16, 32);
+        else if (shape == 2) LP_EXPAND(16, 57);
         else LP_EXPAND(32, 32);
 #undef LP_EXPAND
         ++launches;

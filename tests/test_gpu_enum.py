@@ -176,7 +176,7 @@ def test_prefix_matches_oracle(ctx, m, n, seed):
 # general leaf kernel over the same depth m-7 records
 
 WIDE_SHAPES = [(17, 23, 81), (18, 24, 82), (20, 25, 83), (8, 26, 84), (7, 30, 85), (9, 27, 86),
-               (24, 28, 87), (17, 20, 88), (7, 39, 89)]
+               (24, 28, 87), (17, 20, 88), (7, 39, 89), (7, 46, 92)]
 
 
 @pytest.mark.parametrize("m,n,seed", WIDE_SHAPES)
@@ -204,6 +204,24 @@ def test_wide_prefix_matches_oracle(ctx, m, n, seed):
         v = p.vertex(k)
         _, xB, zz = o.enum_subset(A, b, c, o.unrank(n, m, k))
         assert v["obj"] == zz == gz and np.array_equal(v["x"][v["basis"]], xB)
+    p.free()
+
+
+@pytest.mark.parametrize("m,n,seed", [(9, 64, 93), (16, 64, 94), (32, 64, 95), (20, 52, 96)])
+def test_widest_shapes_windows(ctx, m, n, seed):
+    """The largest shapes the library takes (n = 64: up to 57 selectable columns on 16-row records; m = 32
+    rows; C(64,32) = 1.8e18 ranks): windows of the rank space against the oracle, on the shared-prefix path
+    and on the direct kernel."""
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    p = ctx.enum_problem(A, b, c, True)
+    w = 20_000 if m >= 20 else 50_000
+    for lo in (0, total // 3, total - w):
+        ref = o.enum_range(A, b, c, True, lo, lo + w)
+        assert p.range(lo, lo + w, capi.ENUM_PREFIX)[:3] == ref, (m, n, lo)
+        assert p.range(lo, lo + w, capi.ENUM_DIRECT)[:3] == ref, (m, n, lo)
+        if ref[0] == 0:
+            assert p.first_within(lo, lo + w, ref[1]) == o.enum_first_within(A, b, c, True, lo, lo + w, ref[1])
     p.free()
 
 
@@ -602,10 +620,12 @@ def test_feasible_list_spills_into_subranges(ctx, monkeypatch):
 
 def test_feasible_list_grows_and_is_evaluated_from_records(ctx, monkeypatch):
     """The same degenerate LPs on the default route: the pass that overflows the list reports the number
-    of feasible subsets, the list is re-allocated to hold them and the pass runs once more; every entry's
-    objective then comes from the depth m-7 record it was found under (k_enum_eval_records).  Counts,
-    optimum and the tie rule's rank against the oracle, and bit-identical to the from-scratch evaluation
-    of the direct kernel."""
+    of feasible subsets.  More than a third of the range (or a list 16x over capacity): the dense form —
+    no list, the general leaf kernel writes every subset's score by rank (all rows zero below).  Fewer:
+    the list is re-allocated to hold them and the pass runs once more; every entry's objective then
+    comes from the depth m-7 record it was found under (k_enum_eval_records).  Counts, optimum and the
+    tie rule's rank against the oracle, and bit-identical to the from-scratch evaluation of the direct
+    kernel; a second pass over a sub-range starts in the form the first one ended in."""
     monkeypatch.setenv("LP_ENUM_LIST_START", "300")
     for seed, m, n, zero_rows in [(71, 8, 18, 8), (72, 8, 18, 5), (73, 10, 20, 10), (74, 7, 17, 7), (75, 12, 22, 9)]:
         A, b, c, _ = lpcases.random_lp(seed, m, n)
