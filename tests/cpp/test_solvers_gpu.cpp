@@ -168,6 +168,29 @@ TEST(Enumeration_MultiGpuShardsOnOneDevice) {
     CHECK(EnumerationSolver(nofeas).solve_ex(2, false).status == LP_INFEASIBLE);
     CHECK_THROWS(EnumerationSolver(nofeas).solve_ex(3), std::runtime_error);
 }
+TEST(Enumeration_WideShape) {
+    // 18 rows (more than the 16 of the tuned leaf kernels): C(28,18) = 13.1 M bases on 32-row records and
+    // the general leaf kernel; the simplex solver is the cross-check (README.md:42), and the answer
+    // does not depend on the number of shards.
+    unsigned long long st = 4242;
+    auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(st >> 11) / 9007199254740992.0; };
+    const int m = 18, no = 10;
+    MatrixXd A(m, no);
+    VectorXd b(m), c(no);
+    for (int j = 0; j < no; ++j) { c[j] = rnd(); for (int i = 0; i < m; ++i) A(i, j) = rnd(); }
+    for (int i = 0; i < m; ++i) b[i] = (1.0 + rnd()) * no * 0.5;
+    auto can = Symmetrical(A, b, c, true).ToCanonical();
+    auto simplex = Solver(*can).solve_ex();
+    auto one = EnumerationSolver(*can).solve_ex(1);
+    CHECK(one.status == LP_OPTIMAL);
+    CHECK(one.feasible + one.infeasible + one.singular == lp_binom(m + no, m));
+    CHECK(std::fabs(one.objective - simplex.objective) <= 1e-10 * std::fabs(simplex.objective));
+    for (int j = 0; j < no; ++j) CHECK(std::fabs(one.x[j] - simplex.x[j]) <= 1e-9 * (1 + std::fabs(simplex.x[j])));
+    auto three = EnumerationSolver(*can).solve_ex(3);
+    CHECK(three.status == LP_OPTIMAL && three.rank == one.rank && three.objective == one.objective);
+    CHECK(three.feasible == one.feasible && three.infeasible == one.infeasible && three.singular == one.singular);
+    CHECK(three.basis == one.basis);
+}
 TEST(Enumeration_RcclExchange) {
     // The RCCL communicator of the C ABI (ncclCommInitRank + ONE ncclAllGather of the 48-byte
     // record) with as many shards as this box has devices — one on a one-GPU box, where it still
