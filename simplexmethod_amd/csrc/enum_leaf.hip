@@ -33,6 +33,8 @@
 //            (pivot row = select chain), then the 2x2 block -> x_a, x_b.
 //   phase 2  each of the m-KD rows used by the prefix streams through: KD+1 reads, the same
 //            eliminations against the stored pivot rows, back-substitution, x >= -1e-9.
+#include <type_traits>
+
 #include "enum_tree.hpp"
 
 using namespace lptree;
@@ -315,6 +317,35 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
         s_b6[threadIdx.x] = (unsigned int)d.binom[threadIdx.x * kBinomK + KD];
     }
     __syncthreads();
+    // s_n1[R]: table-1 items of a child with R selectable columns whose whole rank interval lies inside
+    // [begin, end) — the count pass below then costs such a child one lookup instead of the group loop
+    // (nearly every child of a pass is one; the count pass was ~40 % of this kernel, which is 10 % of
+    // an 8-way shard's run time)
+    __shared__ int s_n1[NMX + KD + 2];
+    if (threadIdx.x < NMX + KD + 2) {
+        const int R = threadIdx.x;
+        int n1 = 0, pack_ng = 0;
+        unsigned long long pack_n = 0;
+        for (int j2 = 0; R - 1 - j2 >= kGrandMin; ++j2) {
+            const unsigned long long cnt2 = s_b5[R - 1 - j2];
+            if (cnt2 >= (unsigned long long)kChunk) {
+                n1 += pack_ng ? 1 : 0;
+                pack_ng = 0;
+                pack_n = 0;
+                n1 += (int)((cnt2 + kChunk - 1) / kChunk);
+            } else {
+                if (pack_n + cnt2 > (unsigned long long)kChunk) {
+                    n1 += pack_ng ? 1 : 0;
+                    pack_ng = 0;
+                    pack_n = 0;
+                }
+                ++pack_ng;
+                pack_n += cnt2;
+            }
+        }
+        s_n1[R] = n1 + (pack_ng ? 1 : 0);
+    }
+    __syncthreads();
     const int n = d.n, m = d.m, D = m - KD - (FUSED ? 1 : 0);
     const int nroots = min(pd.level_counts[root_level], root_cap);
     // kItemLanes lanes share a record: lane `sub` takes the children sub, sub + kItemLanes, ... (the
@@ -335,7 +366,58 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
         for (unsigned long long lo = lo0; lo < hi0; lo += kChunk)
             if (overlap(base + lo, (hi0 - lo < kChunk) ? hi0 - lo : (unsigned long long)kChunk, begin, end)) f((int)lo);
     };
-    auto visit = [&](auto&& emit) {   // emit(table, a_field, first subset, rank offset)
+    // one child a (R selectable columns, L subsets from rank rb) of this lane's share
+    auto child = [&](int a, int R, unsigned long long L, unsigned long long rb, int lim, auto&& emit) {
+        // groups j2 = 0, 1, ... with at least kGrandMin columns left; consecutive small
+        // groups are packed into one item (the child pivot is paid once per item)
+        unsigned long long off2 = 0, pack_off = 0, pack_n = 0;
+        int pack_j2 = 0, pack_ng = 0;
+        auto flush = [&]() {
+            if (pack_ng && overlap(rb + pack_off, pack_n, begin, end))
+                emit(1, a | (pack_j2 << 8) | (pack_ng << 16), 0, (int)(rb + pack_off - rb0));
+            pack_ng = 0;
+            pack_n = 0;
+        };
+        for (int j2 = 0; R - 1 - j2 >= kGrandMin; ++j2) {
+            const unsigned long long cnt2 = s_b5[R - 1 - j2];
+            if (cnt2 >= (unsigned long long)kChunk) {
+                flush();
+                chunks(rb + off2, 0, cnt2,
+                       [&](int lo) { emit(1, a | (j2 << 8) | (1 << 16), lo, (int)(rb + off2 - rb0)); });
+            } else {
+                if (pack_n + cnt2 > (unsigned long long)kChunk) flush();
+                if (pack_ng == 0) {
+                    pack_j2 = j2;
+                    pack_off = off2;
+                }
+                ++pack_ng;
+                pack_n += cnt2;
+            }
+            off2 += cnt2;
+        }
+        flush();
+        // table 0: what is left of the child, [off2, L) — at most C(kGrandMin, 6) subsets.
+        // Children 2k and 2k+1 of a record share one item (k_enum_leaves<1> pivots both
+        // from the one record and fills its passes from both tails), emitted by the even one.
+        const bool odd = (a - last - 1) & 1;
+        const bool mine = overlap(rb + off2, L - off2, begin, end) != 0ULL;
+        bool partner = false;   // does the other child of the pair exist and overlap?
+        if (!odd && a + 1 <= lim && n - 2 - a >= min_child_R) {
+            const int Rn = R - 1;
+            unsigned long long offn = 0;
+            for (int j2 = 0; Rn - 1 - j2 >= kGrandMin; ++j2) offn += s_b5[Rn - 1 - j2];
+            partner = overlap(rb + L + offn, s_b6[Rn] - offn, begin, end) != 0ULL;
+        }
+        if (odd) {
+            // (its tail rides in the even child's item: that one is emitted whenever either
+            // tail meets the range)
+        } else if (mine || partner) {
+            emit(0, a | (partner ? 1 << 16 : 0), (int)off2, (int)(rb - rb0));
+        }
+    };
+    // COUNT: only the number of items per table is wanted — a child whose whole interval lies inside
+    // the range takes its table-1 count from s_n1 and (even children) one table-0 item
+    auto visit = [&](auto&& emit, auto count_only) {   // emit(table, a_field, first subset, rank offset)
         if (last == kHole) return;
         if (FUSED) {
             unsigned long long rb = rb0;
@@ -344,51 +426,11 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
                 const int R = n - 1 - a;
                 const unsigned long long L = s_b6[R];
                 if (R >= min_child_R && ((a - last - 1) >> 1) % kItemLanes == sub) {
-                    // groups j2 = 0, 1, ... with at least kGrandMin columns left; consecutive small
-                    // groups are packed into one item (the child pivot is paid once per item)
-                    unsigned long long off2 = 0, pack_off = 0, pack_n = 0;
-                    int pack_j2 = 0, pack_ng = 0;
-                    auto flush = [&]() {
-                        if (pack_ng && overlap(rb + pack_off, pack_n, begin, end))
-                            emit(1, a | (pack_j2 << 8) | (pack_ng << 16), 0, (int)(rb + pack_off - rb0));
-                        pack_ng = 0;
-                        pack_n = 0;
-                    };
-                    for (int j2 = 0; R - 1 - j2 >= kGrandMin; ++j2) {
-                        const unsigned long long cnt2 = s_b5[R - 1 - j2];
-                        if (cnt2 >= (unsigned long long)kChunk) {
-                            flush();
-                            chunks(rb + off2, 0, cnt2,
-                                   [&](int lo) { emit(1, a | (j2 << 8) | (1 << 16), lo, (int)(rb + off2 - rb0)); });
-                        } else {
-                            if (pack_n + cnt2 > (unsigned long long)kChunk) flush();
-                            if (pack_ng == 0) {
-                                pack_j2 = j2;
-                                pack_off = off2;
-                            }
-                            ++pack_ng;
-                            pack_n += cnt2;
-                        }
-                        off2 += cnt2;
-                    }
-                    flush();
-                    // table 0: what is left of the child, [off2, L) — at most C(kGrandMin, 6) subsets.
-                    // Children 2k and 2k+1 of a record share one item (k_enum_leaves<1> pivots both
-                    // from the one record and fills its passes from both tails), emitted by the even one.
-                    const bool odd = (a - last - 1) & 1;
-                    const bool mine = overlap(rb + off2, L - off2, begin, end) != 0ULL;
-                    bool partner = false;   // does the other child of the pair exist and overlap?
-                    if (!odd && a + 1 <= lim && n - 2 - a >= min_child_R) {
-                        const int Rn = R - 1;
-                        unsigned long long offn = 0;
-                        for (int j2 = 0; Rn - 1 - j2 >= kGrandMin; ++j2) offn += s_b5[Rn - 1 - j2];
-                        partner = overlap(rb + L + offn, s_b6[Rn] - offn, begin, end) != 0ULL;
-                    }
-                    if (odd) {
-                        // (its tail rides in the even child's item: that one is emitted whenever either
-                        // tail meets the range)
-                    } else if (mine || partner) {
-                        emit(0, a | (partner ? 1 << 16 : 0), (int)off2, (int)(rb - rb0));
+                    if (decltype(count_only)::value && rb >= begin && rb + L <= end) {
+                        for (int k = 0; k < s_n1[R]; ++k) emit(1, 0, 0, 0);
+                        if (!((a - last - 1) & 1)) emit(0, 0, 0, 0);
+                    } else {
+                        child(a, R, L, rb, lim, emit);
                     }
                 }
                 rb += L;
@@ -398,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
         }
     };
     int nch[2] = {0, 0};
-    visit([&](int tab, int, int, int) { ++nch[tab]; });
+    visit([&](int tab, int, int, int) { ++nch[tab]; }, std::true_type{});
     // slots: wave scan, then ONE atomic per block and table (a returning atomic on one word costs
     // ~11 ns chip-wide; at one per wave they were most of this kernel's time)
     __shared__ int s_wave_total[2][16], s_block_base[2];
@@ -434,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
         const int cap = tab ? pd.item_cap2 : pd.item_cap;
         const int k = tab ? at[1]++ : at[0]++;
         if (k < cap) items[k] = make_int4(rec, a, lo, roff);
-    });
+    }, std::false_type{});
 }
 
 // MODE 1: work items of table 0 over the depth m-7 records; the wave pivots on the child column
