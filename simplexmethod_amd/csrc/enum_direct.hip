@@ -499,23 +499,6 @@ int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* su
     return LP_OPTIMAL;
 }
 
-int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best) {
-    lp_context* ctx = p->ctx;
-    const EnumDev& d = p->dev;
-    const size_t shm = enum_smem_bytes(d);
-    const unsigned grid = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>(count, 16), (uint64_t)ctx->num_cus * 8);
-    if (d.m <= 16)
-        hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, p->prefix.list,
-                           (unsigned long long)count, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores);
-    else
-        hipLaunchKernelGGL((k_enum_eval_list<32>), grid, 256, shm, ctx->stream, d, p->prefix.list,
-                           (unsigned long long)count, (const unsigned long long*)nullptr, 0ULL, p->prefix.scores);
-    int rc = fetch_result(p);
-    if (rc) return rc;
-    *score_best = lp_key_f64(p->h_result->best_key);
-    return LP_OPTIMAL;
-}
-
 // Queues, behind the kernels that fill the feasible list, its evaluation and the tie rule against
 // the list's own best score (tolerance tol) — no host round trip: the caller synchronises once and
 // finds best_key and first_rank in the result block.

@@ -130,8 +130,6 @@ int lp_enum_direct_first(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
                          double tol, uint64_t* rank_out);
 int lp_enum_direct_vertex(lp_enum_problem* p, uint64_t rank, double* xB, int* subset, double* z,
                           int* verdict);
-// objectives of the prefix path's feasible list (scores[] and the best score)
-int lp_enum_eval_list(lp_enum_problem* p, uint64_t count, double* score_best);
 // smallest listed rank whose score is within tol of score_star (UINT64_MAX if none)
 int lp_enum_list_first(lp_enum_problem* p, double score_star, double tol, uint64_t* rank_out);
 // evaluation + tie rule against the list's own best, queued without a host round trip; records !=
