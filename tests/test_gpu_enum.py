@@ -335,7 +335,7 @@ def test_prefix_all_singular(ctx):
     p.free()
 
 
-@pytest.mark.parametrize("m,n", [(8, 20), (9, 24)])
+@pytest.mark.parametrize("m,n", [(8, 20), (9, 24), (17, 21), (7, 26)])   # the last two: general leaf kernel
 def test_prefix_nan_and_inf_entries(ctx, m, n):
     """NaN / inf in the data: a NaN is never a pivot maximum, and a subset whose solution holds a
     NaN counts as infeasible (Canonical.cpp:171 compares x >= -1e-9) — same verdicts, subset by
@@ -646,6 +646,32 @@ def test_feasible_list_grows_and_is_evaluated_from_records(ctx, monkeypatch):
         p.free()
 
 
+def test_fuzz_structured_problems_wide(ctx):
+    """Structured data (integers in {-1, 0, 1, 2}: ties, zero pivots, duplicate and zero columns, singular
+    prefixes pruning whole subtrees) on the general leaf kernel's shapes — 32-row records and more than 16
+    selectable columns — both senses, degenerate right-hand sides included: counts, optimum and the tie
+    rule's rank against the oracle, on both kernels."""
+    rng = np.random.default_rng(78)
+    shapes = [(17, 20), (18, 21), (20, 23), (7, 24), (8, 25), (7, 27), (19, 22), (24, 27)]
+    for trial in range(24):
+        m, n = shapes[trial % len(shapes)]
+        A = rng.integers(-1, 3, size=(m, n)).astype(np.float64)
+        if trial % 3 == 0:
+            A[:, n - m:] += np.eye(m)          # fewer singular bases
+        b = rng.integers(0, 4, size=m).astype(np.float64)
+        c = rng.integers(-2, 3, size=n).astype(np.float64)
+        maximize = bool(rng.integers(0, 2))
+        total = o.binom(n, m)
+        ref = o.enum_range(A, b, c, maximize, 0, total)
+        p = ctx.enum_problem(A, b, c, maximize)
+        for algo in (capi.ENUM_DIRECT, capi.ENUM_PREFIX):
+            got = p.range(0, total, algo)[:3]
+            assert got == ref, (trial, m, n, algo)
+            if ref[0] == 0:
+                assert p.first_within(0, total, ref[1]) == o.enum_first_within(A, b, c, maximize, 0, total, ref[1])
+        p.free()
+
+
 def test_fuzz_small_structured_problems(ctx):
     """150 small problems with integer data in {-1, 0, 1, 2} (ties, zero pivots, duplicate columns
     everywhere), both senses: counts, optimum and the tie rule's rank against the oracle — on the
@@ -661,7 +687,7 @@ def test_fuzz_small_structured_problems(ctx):
         total = o.binom(n, m)
         ref = o.enum_range(A, b, c, maximize, 0, total)
         p = ctx.enum_problem(A, b, c, maximize)
-        algos = [capi.ENUM_DIRECT] + ([capi.ENUM_PREFIX] if 6 <= m <= 16 and 2 <= n - m <= 16 else [])
+        algos = [capi.ENUM_DIRECT] + ([capi.ENUM_PREFIX] if 6 <= m <= 16 and 2 <= n - m else [])
         for algo in algos:
             got = p.range(0, total, algo)[:3]
             assert got == ref, (trial, m, n, algo)
