@@ -767,6 +767,8 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     d.m = m;
     d.n = n;
     d.lda = n + 1;
+    d.rs = m > 16 ? ((m + 1) & ~1) : 16;   // row stride of the shared-prefix records (enum_tree.hpp: rec_rs)
+    d.pad0 = 0;
     d.maximize = maximize ? 1 : 0;
     p->chunk_cap = 1 << 17;
     std::vector<double> Arow((size_t)m * d.lda, 0.0);

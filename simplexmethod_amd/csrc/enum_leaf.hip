@@ -67,6 +67,7 @@ struct LeafObj {
     int D;                        // depth of the record
     int col0;                     // original column of tableau column 0
     unsigned used;                // PERM: rows used by the prefix (row i sits at KD + #used rows below i)
+    int stride;                   // STRIDE == 0: column stride of the tableau (32-row records: EnumDev::rs)
     double z;
 };
 
@@ -74,6 +75,8 @@ template <int KD, int STRIDE, bool PERM, bool OBJ = false>
 __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
                                             unsigned used, double minp0, double maxp0, int m,
                                             LeafObj* obj = nullptr) {
+    // column stride: a template constant, or (STRIDE == 0, list evaluation from 32-row records) obj->stride
+    const int S = STRIDE > 0 ? STRIDE : obj->stride;
     // ---- phase 1: unused rows x chosen columns
     double E[KD][KD], H[KD];
     // PERM (tableau in LDS): step 0's pivot row is chosen BEFORE the rows are loaded — the entries
@@ -89,8 +92,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     double big0 = -1.0, bigs1 = -1.0;
     if constexpr (PERM) {
         double col0[KD], col1[KD];
-        const double* cz = tab + c[0] * STRIDE;
-        const double* cy = tab + c[1] * STRIDE;
+        const double* cz = tab + c[0] * S;
+        const double* cy = tab + c[1] * S;
 #pragma unroll
         for (int r = 0; r < KD; ++r) {
             col0[r] = cz[r];
@@ -132,21 +135,21 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         }
 #pragma unroll
         for (int t = 0; t < KD; ++t) {
-            const double* col = tab + c[t] * STRIDE;
+            const double* col = tab + c[t] * S;
 #pragma unroll
             for (int r = 0; r < KD; ++r) E[r][t] = col[row[r]];
         }
 #pragma unroll
-        for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + row[r]];
+        for (int r = 0; r < KD; ++r) H[r] = tab[R * S + row[r]];
     } else {
 #pragma unroll
         for (int t = 0; t < KD; ++t) {
-            const double* col = tab + c[t] * STRIDE;
+            const double* col = tab + c[t] * S;
 #pragma unroll
             for (int r = 0; r < KD; ++r) E[r][t] = col[U[r]];
         }
 #pragma unroll
-        for (int r = 0; r < KD; ++r) H[r] = tab[R * STRIDE + U[r]];
+        for (int r = 0; r < KD; ++r) H[r] = tab[R * S + U[r]];
     }
     // Invariant: before step t, rows t..KD-1 of E are the rows not yet used, in ascending
     // original order (so "first row of largest |entry|" keeps its meaning), and rows 0..t-1
@@ -244,8 +247,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     auto one_row = [&](int i, bool has) {
         double v[KD];
 #pragma unroll
-        for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * STRIDE + i];
-        double h = tab[R * STRIDE + i];
+        for (int t = 0; t < KD; ++t) v[t] = tab[c[t] * S + i];
+        double h = tab[R * S + i];
 #pragma unroll
         for (int t = 0; t < KD - 2; ++t) {
             const double lx = -(v[t] * INV[t]);
@@ -925,8 +928,8 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
     const int rec = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long lo0 = 0, hi0 = 0;
     if (rec < nrec) {
-        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(roots + (size_t)rec * rec_doubles_g<PGT>(n, D) +
-                                                               (size_t)PGT * (n - D + 1));
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(roots + (size_t)rec * rec_doubles_g<PGT>(n, D, d.rs) +
+                                                               (size_t)rec_rs<PGT>(d.rs) * (n - D + 1));
         const int last = pm->last_col;
         const int R = n - 1 - last;
         if (last != kHole && R >= KD) {
@@ -1013,23 +1016,26 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
         if (item >= nitems) break;
         const int4 it = pd.items[item];
         const int rec = __builtin_amdgcn_readfirstlane(it.x);
-        const double* Q = roots + (size_t)rec * rec_doubles_g<PGT>(n, D);
-        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)PGT * (n - D + 1));
+        const double* Q = roots + (size_t)rec * rec_doubles_g<PGT>(n, D, d.rs);
+        const int RS = rec_rs<PGT>(d.rs);   // row stride of the record's columns in HBM
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)RS * (n - D + 1));
         const int last = __builtin_amdgcn_readfirstlane(pm->last_col);
         const int R = n - 1 - last;
         const unsigned umask = __builtin_amdgcn_readfirstlane(pm->used_mask);
         const unsigned long long rb = pm->rank_base;
         const double minp0 = pm->minp, maxp0 = pm->maxp;
         if (rec != staged) {
-            // columns last+1 .. n-1 and the rhs, PGT rows each; a lane's row is the same in every round
-            const int row = lane & (PGT - 1);
+            // columns last+1 .. n-1 and the rhs, RS rows each: 64 / PGT columns per round, a lane's row is
+            // the same in every round
+            const int row = lane & (PGT - 1), cl = lane / PGT;
             const unsigned all = m >= 32 ? ~0u : ((1u << m) - 1u), below = (1u << row) - 1u, freem = ~umask & all;
             const int pos = (row >= m) ? row
                             : ((freem >> row) & 1u) ? __builtin_popcount(freem & below)
                                                     : __builtin_popcount(freem) + __builtin_popcount(umask & all & below);
-            const double* src = Q + (size_t)(last + 1 - D) * PGT;
+            const double* src = Q + (size_t)(last + 1 - D) * RS;
             __builtin_amdgcn_wave_barrier();   // (the previous item's reads of the slice are done)
-            for (int k = lane; k < (R + 1) * PGT; k += 64) tab[(k / PGT) * TSG + pos] = src[k];
+            if (row < RS)
+                for (int col = cl; col <= R; col += 64 / PGT) tab[col * TSG + pos] = src[(size_t)col * RS + row];
             __builtin_amdgcn_wave_barrier();
             staged = rec;
         }
@@ -1063,6 +1069,7 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
                     obj.D = D;
                     obj.col0 = last + 1;
                     obj.used = umask;
+                    obj.stride = TSG;
                     obj.z = 0.0;
                     verdict = leaf_verdict<KD, TSG, true, true>(tab, c, R, U, 0u, minp0, maxp0, m, &obj);
                     const double score = verdict == 0 ? (d.maximize ? obj.z : -obj.z) : -INFINITY;
@@ -1138,8 +1145,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
     for (unsigned long long e = (unsigned long long)blockIdx.x * LEAF_THREADS + tid; e < count;
          e += (unsigned long long)gridDim.x * LEAF_THREADS) {
         const unsigned long long rank = pd.list[e];
-        const double* Q = roots + (size_t)pd.list_rec[e] * rec_doubles_g<PGT>(n, D);
-        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)PGT * (n - D + 1));
+        const double* Q = roots + (size_t)pd.list_rec[e] * rec_doubles_g<PGT>(n, D, d.rs);
+        const int RS = rec_rs<PGT>(d.rs);
+        const NodeMetaT<PGT>* pm = reinterpret_cast<const NodeMetaT<PGT>*>(Q + (size_t)RS * (n - D + 1));
         const int last = pm->last_col;
         const int R = n - 1 - last;
         // the 7 remaining columns: lexicographic unranking inside the R selectable ones
@@ -1170,9 +1178,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_eval_records(EnumDev d, P
         obj.D = D;
         obj.col0 = last + 1;
         obj.used = umask;
+        obj.stride = RS;
         obj.z = 0.0;
-        const double* tab = Q + (size_t)(last + 1 - D) * PGT;   // column q = column last+1+q
-        const int verdict = leaf_verdict<KD, PGT, false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
+        const double* tab = Q + (size_t)(last + 1 - D) * RS;   // column q = column last+1+q
+        const int verdict = leaf_verdict<KD, (PGT == 32 ? 0 : PGT), false, true>(tab, c, R, U, umask, pm->minp, pm->maxp, m, &obj);
         // (listed subsets are feasible by construction; a verdict mismatch would be a bug and shows
         // up as -inf here)
         const double score = verdict == 0 ? (d.maximize ? obj.z : -obj.z) : -INFINITY;

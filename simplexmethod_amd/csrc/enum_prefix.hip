@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int tid = threadIdx.x;
     constexpr int GW = 64 / PGT;   // groups (children in flight) per wave
     using Meta = NodeMetaT<PGT>;
+    const int RS = rec_rs<PGT>(d.rs);   // row stride of the records' columns
     const int lane = tid & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
     // the level's record count lives on the device (level_counts[t]): the host queues all levels
     // without synchronising, with grids sized for an upper bound
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         const int node = first + tid;
         int nch = 0;
         if (tid < 4 * ppw && node < nsrc) {
-            const Meta* q = reinterpret_cast<const Meta*>(src + (size_t)node * rec_doubles_g<PGT>(n, t) +
-                                                                  (size_t)PGT * (n - t + 1));
+            const Meta* q = reinterpret_cast<const Meta*>(src + (size_t)node * rec_doubles_g<PGT>(n, t, d.rs) +
+                                                                  (size_t)RS * (n - t + 1));
             const int last = q->last_col;
             if (last != kHole) {
                 unsigned long long rb = q->rank_base;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int local = (tid >> 6) * ppw + it;
     const int node = first + local;
     if (node >= nsrc) break;
-    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t);
-    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)PGT * (n - t + 1));
+    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t, d.rs);
+    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)RS * (n - t + 1));
     if (pm.last_col == kHole) continue;
     // ---- the children, one per lane: subset counts, rank bases (exclusive scan), range overlap
     const int a_l = pm.last_col + 1 + lane;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     if (nchild == 0) continue;
     const int wbase = s_base[local];
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-    const double prhs = P[(size_t)(n - t) * PGT + gl];
+    const double prhs = gl < RS ? P[(size_t)(n - t) * RS + gl] : 0.0;
     unsigned long long sing = 0ULL;
     for (int k0 = 0; k0 < nchild; k0 += GW) {
         const int k = k0 + g;                  // this group's child (k-th valid one)
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             if (gl == 0) atomicExch(pd.overflow, 1);
             continue;
         }
-        double* C = dst + (size_t)myslot * rec_doubles_g<PGT>(n, t + 1);
-        Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)PGT * (n - t));
-        const double w = P[(size_t)(a - t) * PGT + gl];
+        double* C = dst + (size_t)myslot * rec_doubles_g<PGT>(n, t + 1, d.rs);
+        Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)RS * (n - t));
+        const double w = gl < RS ? P[(size_t)(a - t) * RS + gl] : 0.0;
         double big;
         const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
         const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
@@ -158,15 +159,15 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
         for (int c0 = a + 1; c0 < n; c0 += 6) {
             double own[6];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) own[u] = (c0 + u < n) ? P[(size_t)(c0 + u - t) * PGT + gl] : 0.0;
+            for (int u = 0; u < 6; ++u) own[u] = (c0 + u < n && gl < RS) ? P[(size_t)(c0 + u - t) * RS + gl] : 0.0;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const double pc = bcast16(own[u], addr);
-                if (c0 + u < n) C[(size_t)(c0 + u - t - 1) * PGT + gl] = fma(lx, pc, isp ? -0.0 : own[u]);
+                if (c0 + u < n && gl < RS) C[(size_t)(c0 + u - t - 1) * RS + gl] = fma(lx, pc, isp ? -0.0 : own[u]);
             }
         }
         const double pr = bcast16(prhs, addr);
-        C[(size_t)(n - t - 1) * PGT + gl] = fma(lx, pr, isp ? -0.0 : prhs);
+        if (gl < RS) C[(size_t)(n - t - 1) * RS + gl] = fma(lx, pr, isp ? -0.0 : prhs);
         if (gl == 0) {
             Meta cm;
             cm.rank_base = rb_child;
@@ -198,13 +199,14 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
     const int m = d.m, n = d.n, S = n - m + 1;   // S = most children a node can have
     constexpr int GW = 64 / PGT;
     using Meta = NodeMetaT<PGT>;
+    const int RS = rec_rs<PGT>(d.rs);   // row stride of the records' columns
     const int lane = threadIdx.x & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
     const int wid = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int node = wid / S, j = wid - node * S;
     const int nsrc = min(pd.level_counts[t], src_cap);
     if (node >= nsrc) return;
-    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t);
-    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)PGT * (n - t + 1));
+    const double* P = src + (size_t)node * rec_doubles_g<PGT>(n, t, d.rs);
+    const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)RS * (n - t + 1));
     const int a = pm.last_col + 1 + j;
     if (pm.last_col == kHole || a > n - m + t) return;
     unsigned long long rb = pm.rank_base;
@@ -218,17 +220,17 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
         if (lane == 0) atomicExch(pd.overflow, 1);
         return;
     }
-    double* C = dst + (size_t)slot * rec_doubles_g<PGT>(n, t + 1);
-    Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)PGT * (n - t));
+    double* C = dst + (size_t)slot * rec_doubles_g<PGT>(n, t + 1, d.rs);
+    Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)RS * (n - t));
     const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
-    const double w = P[(size_t)(a - t) * PGT + gl];
+    const double w = gl < RS ? P[(size_t)(a - t) * RS + gl] : 0.0;
     // this group's columns (a+1+g, a+5+g, ...; column n = the rhs): all loads issued before use
     constexpr int NC = (PGT + NMXT + 1 + GW - 1) / GW;   // n <= PGT + NMXT: at most that many columns + rhs
     double own[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const int c = a + 1 + g + GW * q;
-        own[q] = (c <= n) ? P[(size_t)(c - t) * PGT + gl] : 0.0;
+        own[q] = (c <= n && gl < RS) ? P[(size_t)(c - t) * RS + gl] : 0.0;
     }
     double big;
     const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
     for (int q = 0; q < NC; ++q) {
         const int c = a + 1 + g + GW * q;
         const double pc = bcast16(own[q], addr);
-        if (c <= n) C[(size_t)(c - t - 1) * PGT + gl] = fma(lx, pc, isp ? -0.0 : own[q]);
+        if (c <= n && gl < RS) C[(size_t)(c - t - 1) * RS + gl] = fma(lx, pc, isp ? -0.0 : own[q]);
     }
     if (lane == 0) {
         Meta cm;
@@ -284,9 +286,10 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
         pd.root_cursor[0] = pd.root_cursor[1] = 0;
         pd.item_count[0] = pd.item_count[1] = 0;
     }
-    if (gl >= PGT) return;
-    for (int c = 0; c < d.n; ++c) dst[(size_t)c * PGT + gl] = gl < d.m ? d.A[gl * d.lda + c] : 0.0;
-    dst[(size_t)d.n * PGT + gl] = gl < d.m ? d.b[gl] : 0.0;
+    const int RS = rec_rs<PGT>(d.rs);
+    if (gl >= RS) return;
+    for (int c = 0; c < d.n; ++c) dst[(size_t)c * RS + gl] = gl < d.m ? d.A[gl * d.lda + c] : 0.0;
+    dst[(size_t)d.n * RS + gl] = gl < d.m ? d.b[gl] : 0.0;
     if (gl == 0) {
         NodeMetaT<PGT> cm;
         cm.rank_base = 0ULL;
@@ -295,7 +298,7 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
         cm.last_col = -1;
         cm.used_mask = 0u;
         for (int k = 0; k < PGT; ++k) cm.prow[k] = cm.pcol[k] = 0;
-        *reinterpret_cast<NodeMetaT<PGT>*>(dst + (size_t)PGT * (d.n + 1)) = cm;
+        *reinterpret_cast<NodeMetaT<PGT>*>(dst + (size_t)RS * (d.n + 1)) = cm;
     }
 }
 
@@ -305,7 +308,9 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
 // host driver
 // ---------------------------------------------------------------------------
 
-static size_t host_rec_doubles(int n, int t, int pg) { return (size_t)pg * (n - t + 1) + (pg == 32 ? 12 : 8); }
+static size_t host_rec_doubles(int n, int t, int pg, int rs) {
+    return (size_t)(pg == 32 ? rs : pg) * (n - t + 1) + (pg == 32 ? 12 : 8);
+}
 
 // Number of depth-t tree nodes whose subtree meets the rank range [begin, end): the length-t
 // prefixes of the subsets begin .. end-1 are consecutive in the lexicographic order of the
@@ -381,8 +386,8 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     // range with more depth-D0 nodes than that is split by the caller (kEnumRangeTooWide)
     const uint64_t nodes_max = lp_host_binom(n - m + D0, D0);
     const uint64_t nodes_prev = D0 >= 1 ? lp_host_binom(n - m + D0 - 1, D0 - 1) : 1;
-    const size_t rec_bytes = host_rec_doubles(n, D0, pg) * sizeof(double);
-    const size_t rec_prev_bytes = host_rec_doubles(n, D0 >= 1 ? D0 - 1 : 0, pg) * sizeof(double);
+    const size_t rec_bytes = host_rec_doubles(n, D0, pg, d.rs) * sizeof(double);
+    const size_t rec_prev_bytes = host_rec_doubles(n, D0 >= 1 ? D0 - 1 : 0, pg, d.rs) * sizeof(double);
     uint64_t cap_budget0 = 0, cap_budget1 = 0;   // records the budget allows at depth D0 / D0-1
     {
         if (ctx->total_mem == 0) {
@@ -447,7 +452,7 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     caps[0] = 1;
     for (int t = 0; t < D0; ++t) {
         const int nxt = cur ^ 1;
-        const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1, pg) * sizeof(double));
+        const uint64_t cap64 = p->prefix_buf_bytes[nxt] / (host_rec_doubles(n, t + 1, pg, d.rs) * sizeof(double));
         const int cap = cap64 > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)cap64;
         caps[t + 1] = cap;
         // parents of this level inside the range (exact; the level's holes are among them)

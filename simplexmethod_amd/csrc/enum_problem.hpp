@@ -39,6 +39,8 @@ struct EnumResult {
 struct EnumDev {
     int m, n, lda;                  // lda = n + 1 (odd stride: conflict-free row gathers)
     int maximize;
+    int rs;                         // row stride of 32-row prefix records: m rounded up to even (enum_tree.hpp)
+    int pad0;
     const double* A;                // m x lda row-major copy of the canonical A (pad column 0)
     const double* b;                // m
     const double* c;                // n

@@ -30,9 +30,14 @@ static_assert(sizeof(NodeMetaT<32>) == 96, "NodeMetaT<32> must be 96 bytes");
 // Record of a depth-t node: columns t .. n-1 (PGT doubles each, column-major), then the rhs
 // column, then the node's metadata.  Only columns > last_col are meaningful.
 __host__ __device__ inline size_t rec_doubles(int n, int t) { return (size_t)PG * (n - t + 1) + META; }
+// Row stride of a record's columns: 16 for 16-row records (the tuned kernels index them with
+// shifts); 32-row records store only the problem's rows, m rounded up to even (EnumDev::rs) — at
+// m = 18 a full 32-double column would be 44 % padding, written and read at every level.
 template <int PGT>
-__host__ __device__ inline size_t rec_doubles_g(int n, int t) {
-    return (size_t)PGT * (n - t + 1) + sizeof(NodeMetaT<PGT>) / 8;
+__host__ __device__ inline int rec_rs(int rs_runtime) { return PGT == 32 ? rs_runtime : PGT; }
+template <int PGT>
+__host__ __device__ inline size_t rec_doubles_g(int n, int t, int rs) {
+    return (size_t)rec_rs<PGT>(rs) * (n - t + 1) + sizeof(NodeMetaT<PGT>) / 8;
 }
 
 __device__ __forceinline__ unsigned long long binom(const EnumDev& d, int nn, int kk) {
