@@ -78,21 +78,6 @@ __device__ __forceinline__ double wave_ext_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// Extreme over each 16-lane DPP row (4 steps), valid in every lane of the row.
-template <bool WANT_MAX>
-__device__ __forceinline__ double row16_ext_f64(double v) {
-    double o;
-#define LP_STEP(CTRL)                    \
-    o = dpp_f64<CTRL, 0xF>(v);           \
-    v = WANT_MAX ? fmax(v, o) : fmin(v, o);
-    LP_STEP(LP_DPP_QUAD_XOR1)
-    LP_STEP(LP_DPP_QUAD_XOR2)
-    LP_STEP(LP_DPP_ROW_HALF_MIRROR)
-    LP_STEP(LP_DPP_ROW_MIRROR)
-#undef LP_STEP
-    return v;
-}
-
 __device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), src_lane);
