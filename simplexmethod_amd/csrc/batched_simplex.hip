@@ -72,8 +72,9 @@ __device__ int wave_scan_keyed(int count, double eps, double& best, Get get) {
         get(s, v, k, ok);
         if (ok && k < jM) lp = lpdev::ext2<WANT_MAX>(lp, v);
     }
-    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lp)));
-    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+    // (M beats the extreme P of the entries in front by more than eps iff it beats every lane's share
+    // of them: fl(v + eps) is monotone in v — one ballot instead of a 64-bit key reduction)
+    if (__ballot(!lpdev::beats<WANT_MAX>(M, lp, eps)) == 0ULL) {
         best = M;
         return sM;
     }
@@ -121,8 +122,7 @@ __device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, d
     double lp = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) lp = (lane + 64 * k < jM) ? fmin(lp, rv[k]) : lp;
-    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<false>(lpdev::f64_sort_key(lp)));
-    if (M < P - eps) return jM;
+    if (__ballot(!lpdev::beats<false>(M, lp, eps)) == 0ULL) return jM;   // (one ballot instead of reducing P)
     // near-tie: replay the chain jump by jump
     double best = INFINITY;
     int sel = -1;
@@ -383,8 +383,9 @@ __device__ __forceinline__ int wave_price_select(const double (&dv)[K], const in
 #pragma unroll
     for (int q = 0; q < K; ++q)
         if (kv[q] < jM) lp = lpdev::ext2<WANT_MAX>(lp, dv[q]);
-    const double P = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lp)));
-    if (WANT_MAX ? (M > P + eps) : (M < P - eps)) {
+    // (M beats the extreme P of the entries in front by more than eps iff it beats every lane's share
+    // of them: fl(v + eps) is monotone in v — one ballot instead of a 64-bit key reduction)
+    if (__ballot(!lpdev::beats<WANT_MAX>(M, lp, eps)) == 0ULL) {
         best = M;
         return sM;
     }

@@ -134,7 +134,7 @@ __device__ __forceinline__ void stage_candidate(double up, double xb, bool rowok
     const double ratio = (rowok && up > eps) ? nan_to(xb / up, INFINITY) : INFINITY;   // :185-186
     sh.ratio[tid] = ratio;
     sh.u[tid] = up;
-    lpdev::block_select_stage1<false>(ratio, sh.sc);
+    lpdev::block_select_stage1<false>(ratio, eps, sh.sc);
 }
 
 template <int CPT, bool STAMPS>
@@ -307,7 +307,9 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         __syncthreads();                                                                             \
         RS_STAMP(9);                                                                                \
         if (wave == W2) {                                                                            \
-            const unsigned long long pk = lpdev::wave_ext_key<true>((lane < jl) ? pkey : kNegInf);   \
+            /* does my maximum beat every reduced cost of mine in front of it by more than eps? */   \
+            const double Mk_ = hit ? lpdev::f64_from_key(mkey) : 0.0;                                \
+            const int okp = (hit && __ballot(lane < jl && !(Mk_ > pv + eps)) == 0ULL) ? 1 : 0;        \
             int rk = -2;                                                                             \
             double urk = 0.0;                                                                        \
             if (jl >= 0) {                                                                           \
@@ -316,11 +318,10 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             }                                                                                        \
             /* the two wave-uniform quotients of the update (F(r,r) = 1/u_r, :204, and the reduced-cost   \
                row's -d_e/u_r) are computed HERE, once, off the consumers' critical path */              \
-            const double Mk_ = hit ? lpdev::f64_from_key(mkey) : 0.0;                                \
             const double invk = (rk >= 0) ? 1.0 / urk : 0.0;                                         \
             const double lmk = (rk >= 0) ? -(maximize ? Mk_ : -Mk_) / urk : 0.0;                     \
             if (lane < 5) {                                                                          \
-                const v4i g = lane == 0 ? g_pack(ep, lpdev::f64_from_key(pk))                        \
+                const v4i g = lane == 0 ? g_pack2(ep, okp, 0)                                        \
                             : lane == 1 ? g_pack(ep, urk)                                            \
                             : lane == 2 ? g_pack2(ep, rk, 0)                                         \
                             : lane == 3 ? g_pack(ep, invk) : g_pack(ep, lmk);                        \
@@ -425,21 +426,22 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     b3 = ld16(cm.r, baseB + 48u);
                     b4 = ld16(cm.r, baseB + 64u);
                 }
-                // P = extreme of everything in front of the winner's first maximum: the lanes before the
-                // winner's lane, the records of the winner's own lane in front of the winner (only when a
-                // lane holds several records, G > 64), and P_k* from the winner's record B
-                const unsigned long long Ppk = lpdev::wave_ext_key<true>((lane < W) ? Mlk : kNegInf);
-                double Pin_lane = -INFINITY;
+                // Does M beat everything in front of the winner's first maximum by more than eps?  The
+                // lanes before the winner's lane (one ballot), the records of the winner's own lane in
+                // front of the winner (only when a lane holds several records, G > 64), and the
+                // winner's own verdict on its columns in front of its maximum (record B)
+                const unsigned long long near = __ballot(lane < W && !(M > Ml + eps));
+                int near_lane = 0;
                 if (R > 1 && lane == W) {
                     for (int t = 0; t < R; ++t) {
                         const int q = q0 + t;
                         if (q >= kst) break;
                         const v4i a = ld16(cm.r, cm.recA + (par * (unsigned)G + (unsigned)q) * 32u);
                         const v4i b = ld16(cm.r, cm.recA + (par * (unsigned)G + (unsigned)q) * 32u + 16u);
-                        if (b.y >= 0) Pin_lane = fmax(Pin_lane, g_f64(a));
+                        if (b.y >= 0 && !(M > g_f64(a) + eps)) near_lane = 1;
                     }
                 }
-                Pin_lane = lpdev::wave_bcast_f64(Pin_lane, W);
+                near_lane = __builtin_amdgcn_readlane(near_lane, W);
                 Spin spinB;
                 while (!(g_fresh(b0, ep) && g_fresh(b1, ep) && g_fresh(b2, ep) && g_fresh(b3, ep) && g_fresh(b4, ep))) {
                     if (spinB.expired(cm.r, cm.abort)) {
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                     b3 = ld16(cm.r, baseB + 48u);
                     b4 = ld16(cm.r, baseB + 64u);
                 }
-                const double P = fmax(fmax(lpdev::f64_from_key(Ppk), Pin_lane), g_f64(b0));
+                const bool clear = near == 0ULL && near_lane == 0 && b0.y != 0;
                 ur = g_f64(b1);
                 r = b2.y;
                 inv = g_f64(b3);
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 if (failed) {
                     mode = MODE_FAIL;
                     if (lane == 0) sh.ctl->fail = 6;   // code 6: record B of the winner
-                } else if (M > P + eps) {                // the scan must end on (M, its first index)
+                } else if (clear) {                      // the scan must end on (M, its first index)
                     mode = (r < 0) ? MODE_UNBOUNDED : MODE_PIVOT;
                 } else {
                     mode = MODE_SLOW;
