@@ -261,8 +261,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
     const int R = (G + 63) >> 6;      // records per lane (blocked: lane order = column order)
     const int q0 = lane * R;
     v4i pfa = {0, 0, 0, 0}, pfb = {0, 0, 0, 0};
-    v4i pfB0 = {0, 0, 0, 0}, pfB1 = {0, 0, 0, 0}, pfB2 = {0, 0, 0, 0}, pfB3 = {0, 0, 0, 0},
-        pfB4 = {0, 0, 0, 0};   // record B of record q0 (R == 1 only)
     bool pf = false;
 #define RS_PREFETCH()                                                                     \
     do {                                                                                  \
@@ -299,8 +297,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                                         : g_pack2(ep, jl >= 0 ? col0 + jl : -1, 0);                  \
                 st16(g, cm.r, cm.recA + slot * 32u + (unsigned)lane * 16u, plain);                   \
             }                                                                                        \
-            if (lane < CPT) /* all my reduced costs, for the slow path */                            \
-                st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);    \
         }                                                                                            \
         if (jl >= 0) stage_candidate((UP), (XBV), rowok, eps, ep, cm, cm.col + slot * col_stride, plain, sh); \
         RS_STAMP(8);                                                                                 \
@@ -330,26 +326,15 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
         }                                                                                            \
     } while (0)
 
-    // records B are published later than records A (after the ratio test): their first poll is issued
-    // at the end of the rank-1 update
-#define RS_PREFETCH_B()                                                                   \
-    do {                                                                                  \
-        if (wave == 0 && R == 1 && q0 < G) {                                              \
-            const unsigned base = cm.recB + (par * (unsigned)G + (unsigned)q0) * 96u;     \
-            pfB0 = ld16(cm.r, base);                                                      \
-            pfB1 = ld16(cm.r, base + 16u);                                                \
-            pfB2 = ld16(cm.r, base + 32u);                                                \
-            pfB3 = ld16(cm.r, base + 48u);                                                \
-            pfB4 = ld16(cm.r, base + 64u);                                                \
-        }                                                                                 \
-    } while (0)
+    // (The records B are NOT polled ahead: only the winner's is ever needed, it is published last, and
+    // 32 lanes x 5 granules of speculative polls per workgroup and pivot slowed the stores they were
+    // waiting for — 3.33 -> 3.19 us per pivot without them.)
 
     if (status == kRunning) {   // prologue: candidate of the initial tableau
         RS_PRICE();
         if (jl >= 0) up = RS_SLAB_GET(jl);
         RS_PUBLISH(up, xb);
         RS_PREFETCH();
-        RS_PREFETCH_B();
     }
     while (status == kRunning) {
         RS_STAMP(0);
@@ -407,25 +392,15 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 const int W = (int)__builtin_ctzll(whit);
                 kst = __builtin_amdgcn_readlane(ql, W);
                 e = __builtin_amdgcn_readlane(el, W);
-                // record B of the winner {P_k*, u_r, leaving row}: its loads travel while P is assembled
+                // record B of the winner {verdict on its own columns, u_r, leaving row, 1/u_r, -d_e/u_r}: its loads
+                // travel while the verdict on the other workgroups' maxima is assembled
                 const unsigned baseB = cm.recB + (par * (unsigned)G + (unsigned)kst) * 96u;
                 v4i b0, b1, b2, b3, b4;
-                const bool pfB_ok = R == 1 && g_fresh(pfB0, ep) && g_fresh(pfB1, ep) && g_fresh(pfB2, ep) &&
-                                    g_fresh(pfB3, ep) && g_fresh(pfB4, ep);
-                if (__builtin_amdgcn_readlane((int)pfB_ok, W)) {   // the prefetched copy (lane k* holds record k*)
-                    b0.x = b0.z = b1.x = b1.z = b2.x = b2.z = b3.x = b3.z = b4.x = b4.z = (int)ep;
-                    b0.y = __builtin_amdgcn_readlane(pfB0.y, W); b0.w = __builtin_amdgcn_readlane(pfB0.w, W);
-                    b1.y = __builtin_amdgcn_readlane(pfB1.y, W); b1.w = __builtin_amdgcn_readlane(pfB1.w, W);
-                    b2.y = __builtin_amdgcn_readlane(pfB2.y, W); b2.w = 0;
-                    b3.y = __builtin_amdgcn_readlane(pfB3.y, W); b3.w = __builtin_amdgcn_readlane(pfB3.w, W);
-                    b4.y = __builtin_amdgcn_readlane(pfB4.y, W); b4.w = __builtin_amdgcn_readlane(pfB4.w, W);
-                } else {
-                    b0 = ld16(cm.r, baseB);
-                    b1 = ld16(cm.r, baseB + 16u);
-                    b2 = ld16(cm.r, baseB + 32u);
-                    b3 = ld16(cm.r, baseB + 48u);
-                    b4 = ld16(cm.r, baseB + 64u);
-                }
+                b0 = ld16(cm.r, baseB);
+                b1 = ld16(cm.r, baseB + 16u);
+                b2 = ld16(cm.r, baseB + 32u);
+                b3 = ld16(cm.r, baseB + 48u);
+                b4 = ld16(cm.r, baseB + 64u);
                 // Does M beat everything in front of the winner's first maximum by more than eps?  The
                 // lanes before the winner's lane (one ballot), the records of the winner's own lane in
                 // front of the winner (only when a lane holds several records, G > 64), and the
@@ -488,6 +463,10 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             // ---- exact replay of the scan over all n published reduced costs (near-tie)
             __syncthreads();   // everyone has read the decision before wave 0 rewrites it
             if (wave == 0) {
+                // every workgroup reaches this branch for the same pivot: only now are all the reduced
+                // costs published (a near-tie is rare; storing them with every pivot was 512 bytes per
+                // workgroup of traffic in front of the records)
+                if (lane < CPT) st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);
                 bool failed = false;
                 double best;
                 auto load = [&](int j, bool& ok) {
@@ -666,7 +645,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 for (int j = 0; j < 16; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
             }
         }
-        if (!last) RS_PREFETCH_B();   // the records B are out by now; their round trip runs under the second half
         if (rowok) {
             if (tid != r) {
 #pragma unroll
@@ -693,7 +671,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
 #undef RS_PRICE
 #undef RS_PUBLISH
 #undef RS_PREFETCH
-#undef RS_PREFETCH_B
 
     if (status == kResidentFailed) {   // nothing is written back: the host reruns on another path
         if (tid == 0) {
