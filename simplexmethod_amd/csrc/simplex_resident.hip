@@ -628,7 +628,6 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             }
             RS_PUBLISH(upn, xbn);
             up = upn;
-            RS_PREFETCH();
         }
         RS_STAMP(10);
         // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204);
@@ -645,6 +644,7 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
                 for (int j = 0; j < 16; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
             }
         }
+        if (!last) RS_PREFETCH();   // first poll of the records A: halfway through the update they are mostly out
         if (rowok) {
             if (tid != r) {
 #pragma unroll
