@@ -571,18 +571,18 @@ __global__ __launch_bounds__(512) void k_simplex_resident(SimplexDev d, Resident
             sh.prow[CPT] = xb;
         }
         // ---- entering column: the winner's published candidate (mine is still in a register; after the
-        // slow path it is the owner's second-hop column).  Requested now, awaited after the next pricing.
+        // slow path it is the owner's second-hop column).  Requested behind the pivot-row barrier.
         const bool want_col = kst != k && rowok;
         const unsigned coff = (from_colS ? cm.colS + par * col_stride
                                          : cm.col + (par * (unsigned)G + (unsigned)kst) * col_stride) +
                               (unsigned)tid * 16u;
         v4i gcol = {0, 0, 0, 0};
-        if (want_col) gcol = ld16(cm.r, coff);
         const unsigned ep_col = ep;
         const double inv = cc.inv;   // F(r,r) = 1/u_r, :204
         const double lm = cc.lm;     // F row of the reduced costs: -T[m][e]/u_r
         RS_STAMP(4);
         __syncthreads();
+        if (want_col) gcol = ld16(cm.r, coff);   // awaited after the next pricing
         RS_STAMP(5);
         // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave
         if (colok) {
