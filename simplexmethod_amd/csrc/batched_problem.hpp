@@ -17,7 +17,9 @@ struct BatchedDev {
     int* basis_out;         // batch x m  (by position)
     int* iters;             // batch
     int* status;            // batch
-    unsigned long long* stamps;   // diagnostic (LP_BATCHED_STAMPS=1): 16 per-phase cycle sums of workgroup 0; nullptr = off
+    unsigned long long* stamps;   // diagnostic (LP_BATCHED_STAMPS): 32 per-phase cycle sums of workgroup 0; nullptr = off
+    int stamps_reg;               // LP_BATCHED_STAMPS=reg: the register form's instrumented instantiation (else the LDS form's)
+    int pad_stamps;
 };
 
 // batched_simplex.hip

@@ -435,9 +435,21 @@ __host__ __device__ inline int batched_reg_rpt(int m, int n) {   // rows per upd
 // one-wave scans run under the other's update)
 // DREG: wave 0 keeps the reduced-cost row in registers (12 more VGPRs: not in the 512-thread form,
 // whose 128-VGPR budget is already short).
-template <int NT, int RPT, bool DREG>
+// STAMPS (diagnostic build, LP_BATCHED_STAMPS=reg): cycles of every phase of a pivot as seen by wave 0
+// (the scanning wave) and wave 1 (an updating wave) of workgroup 0, summed in registers.
+template <int NT, int RPT, bool DREG, bool STAMPS = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(BatchedDev d) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+#define BR_STAMP(s)                                                          \
+    do {                                                                     \
+        if (STAMPS) {                                                        \
+            const unsigned long long now_ = __builtin_readcyclecounter();    \
+            acc[(s)] += now_ - tprev;                                        \
+            tprev = now_;                                                    \
+        }                                                                    \
+    } while (0)
     const int m = d.m, n = d.n, nn = n - m, W = nn + 1;
     const int tid = threadIdx.x;
     const int lp = blockIdx.x;
@@ -541,27 +553,32 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
         }
         if (lane == 0) pub[0] = se0;
     };
-    if (wave == 0) price();
-    while (true) {
-        __syncthreads();   // registers and xcol complete, pub[0] published
-        if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
-            status = LP_ITER_LIMIT;
-            break;
-        }
-        const int se = pub[0];
-        if (se < 0) {
-            status = LP_OPTIMAL;
-            break;
-        }
-        // ---- the entering column leaves its owners' registers (:176)
-        if (upd && j == se) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
-        }
-        __syncthreads();
-        // ---- unbounded test (:179), ratios (:185-186) and the ratio test keyed by basis position
-        // (:181-194; +inf entries are never taken): wave 0 alone
-        if (wave == 0) {
+    // The pivot loop exists twice, once per ROLE, with the same sequence of workgroup barriers (a barrier
+    // counts arrivals, not program locations): wave 0 scans (ratio test, reduced costs, pricing) and the
+    // other waves hold the tableau rows.  In one common loop the 88 VGPRs of t[] were live through the
+    // scanning wave's code as well; with 128 VGPRs per thread (two workgroups per CU) the allocator sent
+    // LDS addresses and four rows to SCRATCH, and their global-memory round trips sat inside the ratio
+    // test and the rank-1 update (profiles/r02_batched_stamps.txt).
+    if (STAMPS) tprev = __builtin_readcyclecounter();
+    if (wave == 0) {
+        price();
+        while (true) {
+            __syncthreads();   // (1) registers and xcol complete, pub[0] published
+            BR_STAMP(7);
+            if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
+                status = LP_ITER_LIMIT;
+                break;
+            }
+            const int se = pub[0];
+            if (se < 0) {
+                status = LP_OPTIMAL;
+                break;
+            }
+            BR_STAMP(0);
+            __syncthreads();   // (2) the entering column is in ucol
+            BR_STAMP(1);
+            // ---- unbounded test (:179), ratios (:185-186) and the ratio test keyed by basis position
+            // (:181-194; +inf entries are never taken)
             int r;
             if (m <= 256) {
                 double rv[4];
@@ -590,28 +607,22 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 if (!__any(any_pos)) r = -1;
             }
             if (lane == 0) pub[1] = r;
-        }
-        __syncthreads();
-        const int r = pub[1];
-        if (r < 0) {
-            status = LP_UNBOUNDED;
-            break;
-        }
-        // ---- eta column (:198-204) and the pivot row, from the owners' registers
-        const double ur = ucol[r];
-        const double inv = 1.0 / ur;
-        for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
-        if (tid == 0) lcol[mp] = -drow[se] / ur;
-        const int gr = r / RPT, kr = r % RPT;
-        if (upd && g == gr) {
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                if (k == kr) prow[j] = t[k];
-        }
-        __syncthreads();
-        // ---- rank-1 update; slot se receives the leaving column (the eta column itself)
-        if (wave == 0) {
-            // the reduced-cost row, the basis bookkeeping, then the next pivot's pricing
+            BR_STAMP(2);
+            __syncthreads();   // (3) pub[1] published
+            BR_STAMP(3);
+            if (r < 0) {
+                status = LP_UNBOUNDED;
+                break;
+            }
+            // ---- this wave's share of the eta column (:198-204)
+            const double ur = ucol[r];
+            const double inv = 1.0 / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
+            if (tid == 0) lcol[mp] = -drow[se] / ur;
+            BR_STAMP(4);
+            __syncthreads();   // (4) eta column and pivot row complete
+            BR_STAMP(5);
+            // ---- the reduced-cost row, the basis bookkeeping, then the next pivot's pricing
             const double lm = lcol[mp];
             const int vleave = basis[r];
             if (dreg) {
@@ -632,26 +643,87 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 basis[r] = ve;  // N(leave_pos) = enter, :196
             }
             price();
-        } else if (upd) {
-            const double pj = prow[j];
-            if (j == se) {
+            BR_STAMP(6);
+            ++iters;
+        }
+    } else {
+        while (true) {
+            __syncthreads();   // (1)
+            BR_STAMP(7);
+            if (iters >= d.max_iter) {
+                status = LP_ITER_LIMIT;
+                break;
+            }
+            const int se = pub[0];
+            if (se < 0) {
+                status = LP_OPTIMAL;
+                break;
+            }
+            // ---- the entering column leaves its owners' registers (:176)
+            if (upd && j == se) {
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) t[k] = lcol[g * RPT + k];
-            } else {
+                for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
+            }
+            BR_STAMP(0);
+            __syncthreads();   // (2)
+            BR_STAMP(1);
+            BR_STAMP(2);       // (wave 0 runs the ratio test)
+            __syncthreads();   // (3)
+            BR_STAMP(3);
+            const int r = pub[1];
+            if (r < 0) {
+                status = LP_UNBOUNDED;
+                break;
+            }
+            // ---- eta column (:198-204) and the pivot row, from the owners' registers
+            const double ur = ucol[r];
+            const double inv = 1.0 / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
+            const int gr = r / RPT, kr = r % RPT;
+            if (upd && g == gr) {
+                // (kr is uniform: a switch reaches the one row with a scalar branch tree — 44 predicated
+                // stores were a third of this phase)
+                double v = 0.0;
+                switch (kr) {
+#define BR_CASE(K) case K: v = t[(K) < RPT ? (K) : 0]; break;
+                    BR_CASE(0) BR_CASE(1) BR_CASE(2) BR_CASE(3) BR_CASE(4) BR_CASE(5) BR_CASE(6) BR_CASE(7)
+                    BR_CASE(8) BR_CASE(9) BR_CASE(10) BR_CASE(11) BR_CASE(12) BR_CASE(13) BR_CASE(14) BR_CASE(15)
+                    BR_CASE(16) BR_CASE(17) BR_CASE(18) BR_CASE(19) BR_CASE(20) BR_CASE(21) BR_CASE(22) BR_CASE(23)
+                    BR_CASE(24) BR_CASE(25) BR_CASE(26) BR_CASE(27) BR_CASE(28) BR_CASE(29) BR_CASE(30) BR_CASE(31)
+                    BR_CASE(32) BR_CASE(33) BR_CASE(34) BR_CASE(35) BR_CASE(36) BR_CASE(37) BR_CASE(38) BR_CASE(39)
+                    BR_CASE(40) BR_CASE(41) BR_CASE(42) BR_CASE(43)
+#undef BR_CASE
+                    default: break;
+                }
+                static_assert(RPT <= 44, "extend the switch above");
+                prow[j] = v;
+            }
+            BR_STAMP(4);
+            __syncthreads();   // (4)
+            BR_STAMP(5);
+            // ---- rank-1 update; slot se receives the leaving column (the eta column itself)
+            if (upd) {
+                const double pj = prow[j];
+                if (j == se) {
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) t[k] = fma(lcol[g * RPT + k], pj, t[k]);
-                if (g == gr) {   // the pivot row itself is scaled, not eliminated
+                    for (int k = 0; k < RPT; ++k) t[k] = lcol[g * RPT + k];
+                } else {
 #pragma unroll
-                    for (int k = 0; k < RPT; ++k)
-                        if (k == kr) t[k] = pj * lcol[r];
+                    for (int k = 0; k < RPT; ++k) t[k] = fma(lcol[g * RPT + k], pj, t[k]);
+                    if (g == gr) {   // the pivot row itself is scaled, not eliminated
+#pragma unroll
+                        for (int k = 0; k < RPT; ++k)
+                            if (k == kr) t[k] = pj * lcol[r];
+                    }
+                }
+                if (j == nn) {   // xB for the next ratio test and the final vertex
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) xcol[g * RPT + k] = t[k];
                 }
             }
-            if (j == nn) {   // xB for the next ratio test and the final vertex
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) xcol[g * RPT + k] = t[k];
-            }
+            BR_STAMP(6);
+            ++iters;
         }
-        ++iters;
     }
     __syncthreads();
     // ---- outputs: x(N(t)) = xB(t), zeros elsewhere (:131-132); basis; counters
@@ -666,17 +738,22 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
         d.iters[lp] = iters;
         d.status[lp] = status;
     }
+    if (STAMPS && d.stamps && lp == 0 && (tid == 0 || tid == 64)) {
+        for (int q = 0; q < 8; ++q) d.stamps[(tid ? 16 : 0) + q] = acc[q];
+        d.stamps[(tid ? 16 : 0) + 8] = (unsigned long long)iters;
+    }
+#undef BR_STAMP
 }
 
-template <int NT, int RPT, bool DREG>
+template <int NT, int RPT, bool DREG, bool STAMPS = false>
 static int batched_reg_launch(lp_context* ctx, const BatchedDev& d) {
     const int nn = d.n - d.m, W = nn + 1, G = (NT - 64) / W, mp = G * RPT;
     const size_t dbl = sizeof(Published) / 8 + 2 * (size_t)W + (size_t)(mp + 1) + 2 * (size_t)mp;
     size_t shm = dbl * 8 + sizeof(int) * (size_t)(nn + d.m + d.n);
     shm = (shm + 15) & ~(size_t)15;
-    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG>),
+    LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG, STAMPS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG>), d.batch, NT, shm, ctx->stream, d);
+    hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG, STAMPS>), d.batch, NT, shm, ctx->stream, d);
     return LP_OPTIMAL;
 }
 
@@ -690,6 +767,11 @@ size_t lp_batched_lds_bytes(int m, int n, int* pitch_out) {
 }
 
 int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
+    if (d.stamps && d.stamps_reg) {   // diagnostic build of the default form of BASELINE configs[4]'s shape class
+        if (batched_reg_rpt<512>(d.m, d.n) >= 1 && batched_reg_rpt<512>(d.m, d.n) <= 44)
+            return batched_reg_launch<512, 44, true, true>(ctx, d);
+        LP_FAIL(ctx, LP_BAD_ARG, "LP_BATCHED_STAMPS=reg: the shape does not take the 512-thread register form");
+    }
     if (!d.stamps && !getenv("LP_BATCHED_LDS")) {   // (LP_BATCHED_LDS: A/B against the LDS form)
         // Register-resident form, smallest row array that holds the shape.  Shapes with many rows per
         // thread take the 512-thread form first: two workgroups (two LPs) then share a CU and one LP's
@@ -698,7 +780,7 @@ int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
         const int rpt = batched_reg_rpt<1024>(d.m, d.n), rpt2 = batched_reg_rpt<512>(d.m, d.n);
         if (rpt >= 1 && rpt <= 4) return batched_reg_launch<1024, 4, true>(ctx, d);
         if (rpt >= 1 && rpt <= 12) return batched_reg_launch<1024, 12, true>(ctx, d);
-        if (rpt2 >= 1 && rpt2 <= 44 && !getenv("LP_BATCHED_1024")) return batched_reg_launch<512, 44, false>(ctx, d);
+        if (rpt2 >= 1 && rpt2 <= 44 && !getenv("LP_BATCHED_1024")) return batched_reg_launch<512, 44, true>(ctx, d);
         if (rpt >= 1 && rpt <= 20) return batched_reg_launch<1024, 20, true>(ctx, d);
     }
     const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);

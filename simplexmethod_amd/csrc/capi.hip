@@ -1292,9 +1292,10 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
     if (p->resident) {
         p->dev.eps = eps;
         p->dev.max_iter = max_iter;
-        if (getenv("LP_BATCHED_STAMPS") && !p->dev.stamps) {   // diagnostic build of the kernel (scripts/stamp_batched.py)
-            LP_HIP(ctx, hipMalloc(&p->dev.stamps, sizeof(unsigned long long) * 16));
-            LP_HIP(ctx, hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 16));
+        if (const char* sv = getenv("LP_BATCHED_STAMPS"); sv && !p->dev.stamps) {   // diagnostic build of the kernel (scripts/stamp_batched.py)
+            LP_HIP(ctx, hipMalloc(&p->dev.stamps, sizeof(unsigned long long) * 32));
+            LP_HIP(ctx, hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 32));
+            p->dev.stamps_reg = std::strcmp(sv, "reg") == 0;
         }
         LP_HIP(ctx, hipEventRecord(p->ev0, ctx->stream));
         int rc = lp_batched_launch(ctx, p->dev);
@@ -1306,14 +1307,24 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
         LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
         if (ms_out) *ms_out = ms;
         if (p->dev.stamps) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             LP_HIP(ctx, hipMemcpy(h, p->dev.stamps, sizeof(h), hipMemcpyDeviceToHost));
-            const char* names[6] = {"reduced costs + pricing | rank-1 update", "barrier", "ratio test | (idle)", "barrier",
-                                    "eta column + pivot-row copy", "barrier"};
-            fprintf(stderr, "[batched stamps] workgroup 0, %llu pivots, %.3f ms: cycles per pivot, wave 0 | wave 1\n", h[6], ms);
-            for (int q = 0; q < 6; ++q)
-                fprintf(stderr, "[batched stamps]   %-42s %8.0f | %8.0f\n", names[q], (double)h[q] / (double)(h[6] ? h[6] : 1),
-                        (double)h[8 + q] / (double)(h[14] ? h[14] : 1));
+            if (p->dev.stamps_reg) {
+                const char* names[8] = {"entering column -> LDS", "barrier", "ratio test | (idle)", "barrier",
+                                        "eta column + pivot row -> LDS", "barrier",
+                                        "reduced costs + pricing | rank-1 update", "barrier"};
+                fprintf(stderr, "[batched stamps, register form] workgroup 0, %llu pivots, %.3f ms: cycles per pivot, wave 0 | wave 1\n", h[8], ms);
+                for (int q = 0; q < 8; ++q)
+                    fprintf(stderr, "[batched stamps]   %-42s %8.0f | %8.0f\n", names[q], (double)h[q] / (double)(h[8] ? h[8] : 1),
+                            (double)h[16 + q] / (double)(h[24] ? h[24] : 1));
+            } else {
+                const char* names[6] = {"reduced costs + pricing | rank-1 update", "barrier", "ratio test | (idle)", "barrier",
+                                        "eta column + pivot-row copy", "barrier"};
+                fprintf(stderr, "[batched stamps] workgroup 0, %llu pivots, %.3f ms: cycles per pivot, wave 0 | wave 1\n", h[6], ms);
+                for (int q = 0; q < 6; ++q)
+                    fprintf(stderr, "[batched stamps]   %-42s %8.0f | %8.0f\n", names[q], (double)h[q] / (double)(h[6] ? h[6] : 1),
+                            (double)h[8 + q] / (double)(h[14] ? h[14] : 1));
+            }
         }
         return LP_OPTIMAL;
     }
