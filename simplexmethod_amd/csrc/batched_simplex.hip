@@ -580,7 +580,19 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             // ---- unbounded test (:179), ratios (:185-186) and the ratio test keyed by basis position
             // (:181-194; +inf entries are never taken)
             int r;
-            if (m <= 256) {
+            if (m <= 128) {   // (two ratios per lane: half of the four-per-lane form's work for m <= 128)
+                double rv[2];
+                int any_pos = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int i = lane + 64 * k;
+                    const double ui = (i < m) ? ucol[i] : 0.0;
+                    rv[k] = (i < m && ui > eps) ? xcol[i] / ui : INFINITY;
+                    if (i < m && !(ui <= eps)) any_pos = 1;
+                }
+                r = wave_ratio_select<2>(rv, m, eps);
+                if (!__any(any_pos)) r = -1;
+            } else if (m <= 256) {
                 double rv[4];
                 int any_pos = 0;
 #pragma unroll
