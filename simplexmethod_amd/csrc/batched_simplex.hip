@@ -474,6 +474,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
     // ---- initial condensed tableau for the slack identity basis (Symmetrical.cpp:169-188)
     for (int q = tid; q < n; q += NT) posofvar[q] = -1;
     for (int q = tid; q <= mp; q += NT) lcol[q] = 0.0;
+    if (tid == 0) pubs->v[2] = -1;   // pivot number of the published entering slot (none yet)
     __syncthreads();
     for (int q = tid; q < m; q += NT) {
         basis[q] = bin[q];
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             }
         }
     }
+    bool priced_before_loop = true;   // (the first pricing belongs to pivot 0, the others to pivot iters + 1)
     auto price = [&]() {
         double best;
         int se0;
@@ -551,7 +553,14 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             for (int q = 0; q < 4; ++q)
                 if (lane + 64 * q == se0) drow[se0] = dv[q];
         }
-        if (lane == 0) pub[0] = se0;
+        if (lane == 0) {
+            // the entering slot, then the pivot number it belongs to: the updating waves wait for the
+            // number (LDS writes of one wave land in order) and hand the slot's column over before the
+            // next barrier
+            volatile int* vp = pub;
+            vp[0] = se0;
+            vp[2] = iters + (priced_before_loop ? 0 : 1);
+        }
     };
     // The pivot loop exists twice, once per ROLE, with the same sequence of workgroup barriers (a barrier
     // counts arrivals, not program locations): wave 0 scans (ratio test, reduced costs, pricing) and the
@@ -562,8 +571,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
     if (STAMPS) tprev = __builtin_readcyclecounter();
     if (wave == 0) {
         price();
+        priced_before_loop = false;
         while (true) {
-            __syncthreads();   // (1) registers and xcol complete, pub[0] published
+            __syncthreads();   // (1) registers, xcol and the entering column complete, pub[0] published
             BR_STAMP(7);
             if (iters >= d.max_iter) {  // SimplexSolover.h:429,:450
                 status = LP_ITER_LIMIT;
@@ -575,10 +585,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 break;
             }
             BR_STAMP(0);
-            __syncthreads();   // (2) the entering column is in ucol
             BR_STAMP(1);
             // ---- unbounded test (:179), ratios (:185-186) and the ratio test keyed by basis position
-            // (:181-194; +inf entries are never taken)
+            // (:181-194; +inf entries are never taken); the entering column is in ucol already
             int r;
             if (m <= 128) {   // (two ratios per lane: half of the four-per-lane form's work for m <= 128)
                 double rv[2];
@@ -659,6 +668,19 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             ++iters;
         }
     } else {
+        // ---- the entering column leaves its owners' registers (:176) as soon as wave 0 has priced the
+        // pivot — no phase and no barrier of its own: the updating waves wait for the pivot number
+        // behind their rank-1 update (wave 0 prices meanwhile) and the owners store before barrier (1)
+        auto hand_over = [&]() {
+            volatile int* vp = pub;
+            while (vp[2] != iters) __builtin_amdgcn_s_sleep(1);
+            const int se_next = vp[0];
+            if (upd && se_next >= 0 && j == se_next) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
+            }
+        };
+        hand_over();
         while (true) {
             __syncthreads();   // (1)
             BR_STAMP(7);
@@ -671,13 +693,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 status = LP_OPTIMAL;
                 break;
             }
-            // ---- the entering column leaves its owners' registers (:176)
-            if (upd && j == se) {
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
-            }
             BR_STAMP(0);
-            __syncthreads();   // (2)
             BR_STAMP(1);
             BR_STAMP(2);       // (wave 0 runs the ratio test)
             __syncthreads();   // (3)
@@ -735,6 +751,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             }
             BR_STAMP(6);
             ++iters;
+            hand_over();
         }
     }
     __syncthreads();
