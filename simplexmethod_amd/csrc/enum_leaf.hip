@@ -642,7 +642,11 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             // The child's rows are written PERMUTED: the 6 rows still unused (ascending) at positions
             // 0..5, the used ones (ascending) behind them — leaf_verdict<PERM> then reads every row at
             // a compile-time offset.
-            const unsigned all = (1u << m) - 1u, below = (1u << r) - 1u, freem = ~umask & all;
+            // (`below` is recomputed per item — the opaque copy of r keeps it from being hoisted out of the item
+            // loop, where it was spilled to scratch and reloaded in front of the row permutation)
+            unsigned rr = (unsigned)r;
+            asm volatile("" : "+v"(rr));
+            const unsigned all = (1u << m) - 1u, below = (1u << rr) - 1u, freem = ~umask & all;
             const int pos = (r >= m) ? r
                             : ((freem >> r) & 1u) ? __builtin_popcount(freem & below)
                                                   : __builtin_popcount(freem) + __builtin_popcount(umask & all & below);
@@ -754,11 +758,15 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                     const bool isp = (r == p);
                     const double lx = isp ? inv : -(w * inv);
                     um1 |= 1u << p;
-                    const unsigned all = (1u << m) - 1u, below = (1u << r) - 1u, freem = ~um1 & all;
+                    unsigned rr = (unsigned)r;
+                    asm volatile("" : "+v"(rr));
+                    const unsigned all = (1u << m) - 1u, below = (1u << rr) - 1u, freem = ~um1 & all;
                     const int pos = (r >= m) ? r
                                     : ((freem >> r) & 1u) ? __builtin_popcount(freem & below)
                                                           : __builtin_popcount(freem) + __builtin_popcount(um1 & all & below);
-                    double* ctab1 = s_child2[wave];
+                    int wv = wave;   // (opaque copy: the slice address is recomputed here, not kept live — and spilled — across items)
+                    asm volatile("" : "+v"(wv));
+                    double* ctab1 = s_child2[wv];
 #pragma unroll
                     for (int q = 0; q < (CHILDCOLS + 3) / 4; ++q) {
                         const int j = g + 4 * q;        // column j of the second child = record column child_col+2+j
