@@ -215,7 +215,7 @@ enum {
                                 (bit-identical results, far fewer flops): 6 <= m <= 16 with
                                 2 <= n-m <= 16 on the tuned kernels; 7 <= m <= 16 with any
                                 n <= 64, or 17 <= m <= 32 with n-m <= 32, on the general one;
-                                AUTO takes it for ranges of 2^20 subsets or more         */
+                                AUTO takes it for ranges of 2^15 subsets or more (2^8 for m > 16)         */
 };
 
 typedef struct lp_enum_stats {

@@ -1015,9 +1015,14 @@ int lp_enum_range(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_end, in
         if (stats_out) std::memset(stats_out, 0, sizeof(*stats_out));
         return LP_INFEASIBLE;
     }
-    if (algo == LP_ENUM_ALGO_AUTO)  // the shared-prefix path pays off once the tree is deep and wide
-        algo = (lp_enum_prefix_supported(p) && rank_end - rank_begin >= (1ULL << 20)) ? LP_ENUM_ALGO_PREFIX
-                                                                                        : LP_ENUM_ALGO_DIRECT;
+    if (algo == LP_ENUM_ALGO_AUTO) {
+        // the shared-prefix path pays for its breadth-first levels (0.13-0.25 ms of launches) from ~2^15
+        // subsets on; with 32-row records (m > 16) from the start — the direct kernel's 32-lane form is
+        // five times slower per subset than its 16-lane form (scripts/enum_threshold.py)
+        const int shape = lp_enum_prefix_shape(p);
+        const uint64_t least = shape == 3 ? (1ULL << 8) : (1ULL << 15);
+        algo = (shape != 0 && rank_end - rank_begin >= least) ? LP_ENUM_ALGO_PREFIX : LP_ENUM_ALGO_DIRECT;
+    }
     switch (algo) {
         case LP_ENUM_ALGO_PREFIX:
             if (!lp_enum_prefix_supported(p))

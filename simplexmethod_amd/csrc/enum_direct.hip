@@ -378,11 +378,18 @@ static int launch_direct(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     const int block = 256;
     const int groups_per_block = block / G;
     const uint64_t count = end - begin;
-    // enough groups to fill the chip several times over, but at least ~64 subsets per group
+    // enough groups to fill the chip several times over, with ~64 subsets per group to amortise the
+    // unranking and the block's copy of A — but a SMALL range is spread over every CU first: a group's
+    // subsets are a serial chain (~10 us each at m = 16), and 64 of them in a row were a 0.7-1.7 ms floor
+    // under every small problem (C(13,6) = 1716 subsets, the reference's own examples)
     uint64_t want_groups = (uint64_t)ctx->num_cus * 8 * groups_per_block;
     if (want_groups > (uint64_t)p->chunk_cap) want_groups = p->chunk_cap;
     uint64_t per_chunk = lp_ceil_div<uint64_t>(count, want_groups);
-    if (per_chunk < 64) per_chunk = 64;
+    if (per_chunk < 64) {
+        per_chunk = lp_ceil_div<uint64_t>(count, (uint64_t)ctx->num_cus * groups_per_block);   // one block per CU first
+        if (per_chunk > 64) per_chunk = 64;
+        if (per_chunk < 1) per_chunk = 1;
+    }
     const uint64_t chunks = lp_ceil_div<uint64_t>(count, per_chunk);
     const unsigned grid = (unsigned)lp_ceil_div<uint64_t>(chunks, groups_per_block);
     const size_t shm = enum_smem_bytes(d);
