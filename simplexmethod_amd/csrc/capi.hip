@@ -501,11 +501,16 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
         t_prev = t;
     };
     // make_b_nonneg (:61-68) and createAuxiliaryProblem (:70-95)
+    std::vector<char> flip((size_t)m);
     for (int i = 0; i < m; ++i) {
-        const bool flip = b[i] < -eps;
-        b1[i] = flip ? -b[i] : b[i];
-        for (int j = 0; j < n; ++j) A1[(size_t)j * m + i] = flip ? -A[(size_t)j * m + i] : A[(size_t)j * m + i];
+        flip[i] = b[i] < -eps;
+        b1[i] = flip[i] ? -b[i] : b[i];
         A1[(size_t)(n + i) * m + i] = 1.0;
+    }
+    for (int j = 0; j < n; ++j) {   // (column by column: both matrices are column-major)
+        const double* src = A + (size_t)j * m;
+        double* dst = A1.data() + (size_t)j * m;
+        for (int i = 0; i < m; ++i) dst[i] = flip[i] ? -src[i] : src[i];
     }
     for (int j = n; j < na; ++j) c1[j] = 1.0;
     for (int t = 0; t < m; ++t) N[t] = n + t;
