@@ -127,11 +127,7 @@ def pivot_leg(ctx, args):
             rc_s, st_s = p.run(algo=args.simplex_algo)
         buf = (C.c_ulonglong * 16)()
         ctx.lib.lp_debug_simplex_stamps(p.h, 1, buf)
-        names = ["loop", "poll_records_A", "decide_and_record_B", "decision_barrier",
-                 "read_decision_pivot_row_to_lds_request_column", "pivot_row_barrier",
-                 "reduced_costs_and_next_pricing", "column_wait_eta_entry",
-                 "candidate_publish_ratio_stage1", "ratio_barrier", "ratio_stage2_record_B_prefetch",
-                 "rank1_update_32_columns"]
+        names = capi.RESIDENT_STAMP_NAMES
         cyc = [buf[i] / max(st_s.pivots, 1) for i in range(12)]
         tot = sum(cyc)
         phases = {"instrumented_solve_ms": round(st_s.solve_ms, 3), "cycles_per_pivot_total": round(tot, 1),

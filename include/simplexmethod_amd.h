@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 1
+#define LP_ABI_VERSION 2 /* 2: lp_simplex_stats grew algo_used / fell_back; lp_enum_shard_abstain, lp_batched_shard_bounds */
 
 /* Status codes; the C++ wrappers map them back to the
  * reference's exception types and messages.                                     */
@@ -90,9 +90,13 @@ enum {
     LP_SIMPLEX_ALGO_LOOKAHEAD = 2, /* J pivots staged by a one-workgroup selector, then
                                       one rank-J update pass over the tableau            */
     LP_SIMPLEX_ALGO_RESIDENT = 3   /* one launch per solve: the tableau stays in the registers of
-                                      ceil(n/32) co-resident workgroups (m <= 1024, n <= 8192),
-                                      one all-to-all hand-off per pivot; AUTO's choice when the
-                                      shape fits                                          */
+                                      co-resident workgroups, one per CU (32 columns each for
+                                      m <= 512, 16 columns each for 512 < m <= 1024; at most 256
+                                      workgroups, i.e. n <= 8192 resp. n <= 4096), one all-to-all
+                                      hand-off per pivot; AUTO's choice when the shape fits.  A
+                                      hand-off that times out (the workgroups never became
+                                      co-resident) re-runs the solve on another algorithm:
+                                      lp_simplex_stats::fell_back                          */
 };
 
 typedef struct lp_simplex_stats {
@@ -105,6 +109,10 @@ typedef struct lp_simplex_stats {
                                resident algorithm the one kernel that runs every pivot (always) */
     int update_launches;    /* launches counted in update_ms                               */
     double bytes_per_pivot; /* algorithmic bytes of one rank-1 update: 16*m*(n+1)          */
+    int algo_used;          /* LP_SIMPLEX_ALGO_* that produced the answer (never AUTO)             */
+    int fell_back;          /* 1: the chip-resident algorithm was asked for (or chosen by AUTO), a
+                               hand-off timed out and the solve was re-run on algo_used; the answer is
+                               the same, the solve took >= 200 ms longer.  0 otherwise.              */
 } lp_simplex_stats;
 
 int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const double* b,
@@ -133,7 +141,10 @@ void lp_simplex_free(lp_simplex_problem* p);
  * change sign; phase I minimises the sum of m artificials [A' | I] from their identity basis;
  * LP_INFEASIBLE iff that sum > eps; an artificial still basic leaves for the first non-basic
  * original column with |T[pos][cand]| > eps (none: LP_SINGULAR, dependent constraints); phase II
- * = lp_simplex_solve on (A', b', c) from the clean basis.  Every pivot runs on the GPU.
+ * CONTINUES ON THE PHASE-I TABLEAU: the reduced-cost row is re-priced from the original costs
+ * over the current basis, the artificial columns stay but are barred from entering (no second
+ * upload, no re-inversion; the vertex carries phase I's rounding, ~1e-16 relative).  Every pivot
+ * runs on the GPU.
  * iters_out (optional): 3 ints = pivots of phase I, drive-out pivots, pivots of phase II.       */
 int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const double* b,
                          const double* c, int maximize, int n_orig, double eps, int max_iter,
@@ -181,6 +192,12 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
 int lp_batched_download(lp_batched_problem* p, double* x_out, int* basis_out, double* obj_out,
                         int* iters_out, int* status_out);
 void lp_batched_free(lp_batched_problem* p);
+/* BASELINE.json configs[4] "1 -> 8 GPUs": the LPs of a batch are independent, so participant `shard`
+ * of `shards` (one process or host thread per GPU) uploads and solves the LPs [*lo, *hi) of the batch
+ * and nobody exchanges anything (replicas of the code, no collective; the caller concatenates the
+ * outputs).  The convention every binding uses: *lo = batch*shard/shards, *hi = batch*(shard+1)/shards
+ * (64-bit arithmetic) - contiguous, disjoint, covering, sizes differing by at most one.             */
+int lp_batched_shard_bounds(int batch, int shard, int shards, int* lo, int* hi);
 
 /* =========================================================================
  * Enumeration — EnumerationSolver (src/EnumerationSolver.h:3-10 is a stub; spec
@@ -269,6 +286,12 @@ void lp_comm_destroy(lp_comm* c);
  * exchange, and every participant returns its status).                                          */
 int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double* x_out, int* basis_out,
                           uint64_t* rank_out, double* obj_out, uint64_t* counts_out);
+/* A participant that cannot enumerate (its context, upload or communicator set-up failed) calls this
+ * INSTEAD of lp_enum_solve_sharded, so that the others are not left waiting in the exchange: it
+ * contributes a failed record and returns `status` (LP_BAD_ARG if LP_OPTIMAL was passed); every other
+ * participant's lp_enum_solve_sharded returns that status.  lp_enum_solve_sharded(comm, NULL, ...)
+ * does the same with LP_BAD_ARG.                                                                 */
+int lp_enum_shard_abstain(lp_comm* comm, int status);
 
 #ifdef __cplusplus
 }

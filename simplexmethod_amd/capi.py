@@ -30,7 +30,7 @@ _vp = C.c_void_p
 class SimplexStats(C.Structure):
     _fields_ = [("status", C.c_int), ("pivots", C.c_int), ("launches", C.c_int),
                 ("solve_ms", C.c_float), ("update_ms", C.c_float), ("update_launches", C.c_int),
-                ("bytes_per_pivot", C.c_double)]
+                ("bytes_per_pivot", C.c_double), ("algo_used", C.c_int), ("fell_back", C.c_int)]
 
 
 class EnumStats(C.Structure):
@@ -70,6 +70,7 @@ SIGNATURES = {
     "lp_batched_run": (C.c_int, [_vp, C.c_double, C.c_int, _fp]),
     "lp_batched_download": (C.c_int, [_vp, _dp, _ip, _dp, _ip, _ip]),
     "lp_batched_free": (None, [_vp]),
+    "lp_batched_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "lp_binom": (C.c_uint64, [C.c_int, C.c_int]),
     "lp_enum_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _u64p, _u64p]),
     "lp_enum_solve": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _ip,
@@ -87,7 +88,17 @@ SIGNATURES = {
     "lp_comm_world": (C.c_int, [_vp]),
     "lp_comm_destroy": (None, [_vp]),
     "lp_enum_solve_sharded": (C.c_int, [_vp, _vp, C.c_int, _dp, _ip, _u64p, _dp, _u64p]),
+    "lp_enum_shard_abstain": (C.c_int, [_vp, C.c_int]),
 }
+
+# phases of the chip-resident kernel's diagnostic instantiation (lp_debug_simplex_stamps after a
+# chip-resident run: cycle sums of wave 0 of each workgroup, in this order)
+RESIDENT_STAMP_NAMES = [
+    "loop", "poll_records", "decide", "decision_barrier",
+    "read_decision_pivot_row_to_lds_request_column_two_quotients", "pivot_row_barrier",
+    "reduced_costs_and_next_pricing", "column_wait_eta_entry",
+    "candidate_ratio_stage1", "ratio_barrier", "wave_W2_only_ratio_stage2_and_record",
+    "rank1_update_and_eta_column_publication"]
 
 _lib = None
 

@@ -228,7 +228,8 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
     la.J = lp_lookahead_pick_j(m, n);
     la.rows_pad = ((m + 1 + 7) / 8) * 8;
     const size_t J = (size_t)(la.J > 0 ? la.J : 1);
-    const bool resident = lp_resident_plan(m, n, &p->res) != 0;
+    p->res_v1 = getenv("LP_RESIDENT_V1") != nullptr;   // A/B against the round-2 kernel
+    const bool resident = (p->res_v1 ? lp_resident_plan_v1(m, n, &p->res) : lp_resident_plan(m, n, &p->res)) != 0;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -372,23 +373,33 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     if (algo == LP_SIMPLEX_ALGO_AUTO)
         algo = p->res.G >= 1 ? LP_SIMPLEX_ALGO_RESIDENT
                              : (p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD : LP_SIMPLEX_ALGO_LAUNCH);
+    const int asked = algo;
+    int rc;
     switch (algo) {
         case LP_SIMPLEX_ALGO_RESIDENT:
             if (p->res.G < 1)
-                LP_FAIL(ctx, LP_BAD_ARG, "chip-resident simplex needs m <= 1024 and n <= 8192");
-            return lp_simplex_run_resident(p, eps, max_iter, stats_out);
+                LP_FAIL(ctx, LP_BAD_ARG, "chip-resident simplex needs m <= 1024 and ceil(n / columns per workgroup) <= 256 workgroups");
+            rc = lp_simplex_run_resident(p, eps, max_iter, stats_out);
+            break;
         case LP_SIMPLEX_ALGO_LAUNCH:
-            return lp_simplex_run_launch(p, eps, max_iter, stats_out);
+            rc = lp_simplex_run_launch(p, eps, max_iter, stats_out);
+            break;
         case LP_SIMPLEX_ALGO_LOOKAHEAD: {
             if (p->look.J < 1)
                 LP_FAIL(ctx, LP_BAD_ARG, "look-ahead selector does not fit LDS for this m, n");
-            int rc = lp_lookahead_prepare(p);
+            rc = lp_lookahead_prepare(p);
             if (rc) return rc;
-            return lp_simplex_run_lookahead(p, eps, max_iter, stats_out);
+            rc = lp_simplex_run_lookahead(p, eps, max_iter, stats_out);
+            break;
         }
         default:
             LP_FAIL(ctx, LP_BAD_ARG, "unknown simplex algorithm id");
     }
+    if (stats_out) {   // which algorithm produced the answer (a chip-resident hand-off that timed out is re-run)
+        stats_out->algo_used = p->last_algo;
+        stats_out->fell_back = (asked == LP_SIMPLEX_ALGO_RESIDENT && p->last_algo != LP_SIMPLEX_ALGO_RESIDENT) ? 1 : 0;
+    }
+    return rc;
 }
 
 int lp_simplex_profile(lp_simplex_problem* p, int on) {
@@ -1195,6 +1206,13 @@ void lp_batched_free(lp_batched_problem* p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
+}
+
+int lp_batched_shard_bounds(int batch, int shard, int shards, int* lo, int* hi) {
+    if (batch < 0 || shards < 1 || shard < 0 || shard >= shards || !lo || !hi) return LP_BAD_ARG;
+    *lo = (int)((long long)batch * shard / shards);
+    *hi = (int)((long long)batch * (shard + 1) / shards);
+    return LP_OPTIMAL;
 }
 
 int lp_batched_upload(lp_context* ctx, int batch, const double* A, int m, int n, const double* b,

@@ -299,4 +299,103 @@ __device__ __forceinline__ double ext2(double a, double b) {
     return WANT_MAX ? (a > b ? a : b) : (a < b ? a : b);
 }
 
+// ---------------------------------------------------------------------------
+// Narrow and short-cut forms (round 3).  A lone reducing wave pays every dependent instruction at
+// ~8 cycles, so (1) a reduction over the first N lanes only (N a power of two; lanes >= N must hold
+// the identity) stops after log2 N DPP steps and reads lane N - 1; (2) a 64-bit key extreme reduces
+// the HIGH words first and, when exactly one lane holds the extreme high word (the common case: two
+// candidates agreeing in sign, exponent and 20 mantissa bits are rare), takes the low word straight
+// from that lane — one 6-step pass instead of two.  Ties on the high word take the second pass, so
+// the result is the exact extreme either way.
+// ---------------------------------------------------------------------------
+#define LP_DPP_STEP(OP, CTRL) \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " bank_mask:0xf" : "+v"(v))
+template <bool WANT_MAX, int N>
+__device__ __forceinline__ unsigned wave_ext_u32_n(unsigned v) {
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "N: a power of two, 2..64");
+    if (WANT_MAX) {
+        LP_DPP_STEP("v_max_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf");
+        if (N >= 4) LP_DPP_STEP("v_max_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf");
+        if (N >= 8) LP_DPP_STEP("v_max_u32_dpp", "row_half_mirror row_mask:0xf");
+        if (N >= 16) LP_DPP_STEP("v_max_u32_dpp", "row_mirror row_mask:0xf");
+        if (N >= 32) LP_DPP_STEP("v_max_u32_dpp", "row_bcast:15 row_mask:0xa");
+        if (N >= 64) LP_DPP_STEP("v_max_u32_dpp", "row_bcast:31 row_mask:0xc");
+    } else {
+        LP_DPP_STEP("v_min_u32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf");
+        if (N >= 4) LP_DPP_STEP("v_min_u32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf");
+        if (N >= 8) LP_DPP_STEP("v_min_u32_dpp", "row_half_mirror row_mask:0xf");
+        if (N >= 16) LP_DPP_STEP("v_min_u32_dpp", "row_mirror row_mask:0xf");
+        if (N >= 32) LP_DPP_STEP("v_min_u32_dpp", "row_bcast:15 row_mask:0xa");
+        if (N >= 64) LP_DPP_STEP("v_min_u32_dpp", "row_bcast:31 row_mask:0xc");
+    }
+    asm volatile("s_nop 1" ::: "memory");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, N - 1);
+}
+#undef LP_DPP_STEP
+
+// Extreme of 64-bit sortable keys over the first N lanes (lanes >= N: the identity key).  Returns the
+// extreme key (wave-uniform); *hits = the lanes holding it.
+template <bool WANT_MAX, int N>
+__device__ __forceinline__ unsigned long long wave_ext_key_n(unsigned long long key, unsigned long long* hits) {
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned mhi = wave_ext_u32_n<WANT_MAX, N>(hi);
+    const unsigned long long cand = __ballot(hi == mhi);
+    unsigned mlo;
+    if ((cand & (cand - 1)) == 0ULL) {   // exactly one lane (cand != 0: the extreme is somebody's)
+        mlo = (unsigned)__builtin_amdgcn_readlane((int)lo, (int)__builtin_ctzll(cand));
+        *hits = cand;
+    } else {
+        const unsigned lo2 = (hi == mhi) ? lo : (WANT_MAX ? 0u : 0xFFFFFFFFu);
+        mlo = wave_ext_u32_n<WANT_MAX, N>(lo2);
+        *hits = __ballot(hi == mhi && lo == mlo);
+    }
+    return ((unsigned long long)mhi << 32) | mlo;
+}
+
+// block_select_stage1 / stage2 on those: slices of 64 entries (one per thread), NWMAX = upper bound
+// of the number of waves (power of two).  Same verdicts as the forms above.
+template <bool WANT_MAX>
+__device__ __forceinline__ void block_select_stage1_n(double v, double eps, BlockSelScratch* sc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long skey = f64_sort_key(WANT_MAX ? -INFINITY : INFINITY);
+    const unsigned long long key = f64_sort_key(v);
+    unsigned long long hit;
+    const unsigned long long mk = wave_ext_key_n<WANT_MAX, 64>(key, &hit);
+    const bool any = mk != skey;
+    const int L = any ? (int)__builtin_ctzll(hit) : 64;
+    const unsigned long long near = __ballot(lane < L && !beats<WANT_MAX>(f64_from_key(mk), v, eps));
+    if (lane == 0) {
+        sc->M[wave] = mk;
+        sc->ok[wave] = (any && near == 0ULL) ? 1 : 0;
+        sc->J[wave] = any ? wave * 64 + L : INT_MAX;
+    }
+}
+
+template <bool WANT_MAX, int NWMAX, int K>
+__device__ __forceinline__ int block_select_stage2_n(const double* vals, int len, double eps,
+                                                     const BlockSelScratch* sc) {
+    const int lane = threadIdx.x & 63, nwaves = (int)(blockDim.x >> 6);
+    const unsigned long long skey = f64_sort_key(WANT_MAX ? -INFINITY : INFINITY);
+    const bool has = lane < nwaves;
+    const unsigned long long Ml = has ? sc->M[lane & 15] : skey;
+    const int okl = has ? sc->ok[lane & 15] : 0;
+    const int Jl = has ? sc->J[lane & 15] : INT_MAX;
+    unsigned long long hit;
+    const unsigned long long M = wave_ext_key_n<WANT_MAX, NWMAX>(Ml, &hit);
+    if (M == skey) return -1;
+    const int W = (int)__builtin_ctzll(hit);   // first slice attaining the extreme (slices are in row order)
+    const int jM = __builtin_amdgcn_readlane(Jl, W);
+    const int okW = __builtin_amdgcn_readlane(okl, W);
+    const double Md = f64_from_key(M);
+    const unsigned long long near = __ballot(lane < W && !beats<WANT_MAX>(Md, f64_from_key(Ml), eps));
+    if (okW && near == 0ULL) return jM;
+    double best;   // near-tie: exact replay over the LDS copy
+    auto load = [&](int j, bool& ok) {
+        ok = true;
+        return vals[j];
+    };
+    return wave_chain_select<WANT_MAX, K>(len, eps, best, load);
+}
+
 }  // namespace lpdev

@@ -438,6 +438,10 @@ int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, doubl
     }
     // depth-D0 records always end in buffer 0; levels alternate so that level D0 lands there
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
+    // dense form: only subsets under live depth-D0 records get a score from the leaf kernel; subtrees
+    // pruned as singular leave their entries untouched, and the tie rule scans the whole range.  All
+    // bits set = NaN, which fails its `>=` test (the buffer comes from a pool: old scores, level records)
+    if (dense) LP_HIP(ctx, hipMemsetAsync(pd.dense_scores, 0xFF, sizeof(double) * (end - begin), s));
     int launches = 0;
     int cur = (D0 % 2 == 0) ? 0 : 1;  // buffer of level 0, so that level D0 is buffer 0
     // All levels and the leaf kernel are queued without a host round trip: every level's record

@@ -206,9 +206,25 @@ void lp_comm_destroy(lp_comm* c) {
     delete c;
 }
 
+// A participant that cannot take part in the enumeration (its context, upload or communicator set-up
+// failed) still owes the group its record: the others are waiting in the exchange.  Contributes a
+// failed record (status != LP_OPTIMAL) to the ONE all-gather and returns that status; every other
+// participant's lp_enum_solve_sharded then returns it too.
+int lp_enum_shard_abstain(lp_comm* comm, int status) {
+    if (status == LP_OPTIMAL) status = LP_BAD_ARG;
+    if (!comm) return status;
+    const int world = lp_comm_world(comm);
+    long long rec[kRecWords] = {0, 0x7FFFFFFFFFFFFFFFLL, 0, 0, 0, status};
+    const double none = -INFINITY;
+    std::memcpy(&rec[0], &none, sizeof(double));
+    std::vector<long long> all((size_t)world * kRecWords);
+    const int rc = comm_allgather(comm, rec, kRecWords, all.data());
+    return rc ? rc : status;
+}
+
 int lp_enum_solve_sharded(lp_comm* comm, lp_enum_problem* p, int n_orig, double* x_out, int* basis_out,
                           uint64_t* rank_out, double* obj_out, uint64_t* counts_out) {
-    if (!p) return LP_BAD_ARG;
+    if (!p) return lp_enum_shard_abstain(comm, LP_BAD_ARG);   // nobody is left waiting in the exchange
     lp_context* ctx = p->ctx;
     const int rank = lp_comm_rank(comm), world = lp_comm_world(comm);
     const EnumDev& d = p->dev;

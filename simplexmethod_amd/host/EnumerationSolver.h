@@ -101,6 +101,7 @@ public:
             } else {
                 s.comm = local[(size_t)g];
             }
+            if (s.rc == LP_OPTIMAL && g == _debug_fail_shard) s.rc = LP_BAD_ARG;   // (tests)
             if (s.rc == LP_OPTIMAL) {
                 uint64_t counts[3] = {0, 0, 0};
                 s.rc = lp_enum_solve_sharded(s.comm, s.p, n_orig, s.res.x.data(), s.res.basis.data(), &s.res.rank,
@@ -108,11 +109,18 @@ public:
                 s.res.feasible = counts[0];
                 s.res.infeasible = counts[1];
                 s.res.singular = counts[2];
+            } else {
+                // a shard that cannot enumerate still owes the others its record: they are waiting in
+                // the exchange (a NULL communicator — RCCL set-up failed — has nobody to tell)
+                const std::string why = s.ctx ? lp_last_error(s.ctx) : "";
+                s.rc = lp_enum_shard_abstain(s.comm, s.rc);
+                s.error = why;
             }
-            if (s.rc != LP_OPTIMAL && s.ctx) s.error = lp_last_error(s.ctx);
+            if (s.rc != LP_OPTIMAL && s.ctx && s.error.empty()) s.error = lp_last_error(s.ctx);
             s.res.status = s.rc;
         };
         std::vector<std::thread> th;
+        th.reserve((size_t)n_gpus);   // (the only allocation between lp_comm_create_local and the joins)
         for (int g = 0; g < n_gpus; ++g) th.emplace_back(run, g);
         for (auto& t : th) t.join();
         int rc = LP_OPTIMAL;
@@ -137,7 +145,12 @@ public:
         return r;
     }
 
+    // Tests only: shard g behaves as if its upload had failed (it must still join the exchange and
+    // every shard must come back with its status).
+    void debug_fail_shard(int g) { _debug_fail_shard = g; }
+
 private:
     Canonical _problem;
     int _device;
+    int _debug_fail_shard = -1;
 };

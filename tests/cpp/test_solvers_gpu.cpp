@@ -1,6 +1,8 @@
 // GPU tests of the drop-in C++ solver classes (Solver, EnumerationSolver) against the known
 // answers of SURVEY.md §4 and each other (README.md:42: the enumeration solver cross-checks
 // the simplex solver).
+#include <thread>
+
 #include "check.h"
 #include "Canonical.h"
 #include "Common.h"
@@ -167,6 +169,32 @@ TEST(Enumeration_MultiGpuShardsOnOneDevice) {
     Canonical nofeas(mat(1, 2, {1, 1}), vec({-1}), vec({1, 1}), {0}, false);
     CHECK(EnumerationSolver(nofeas).solve_ex(2, false).status == LP_INFEASIBLE);
     CHECK_THROWS(EnumerationSolver(nofeas).solve_ex(3), std::runtime_error);
+}
+TEST(Enumeration_FailingShardStillJoinsTheExchange) {
+    // One shard cannot enumerate (as if its upload had failed).  It must still contribute its record to the
+    // exchange — otherwise the other shards' threads wait forever — and every shard comes back with its
+    // status.  First, middle and last shard; exchange through host memory (shards share the device).
+    auto can = Symmetrical(mat(2, 3, {1, 2, 3, 4, 5, 6}), vec({10, 20}), vec({7, 8, 3}), true).ToCanonical();
+    for (int bad : {0, 1, 3}) {
+        EnumerationSolver es(*can);
+        es.debug_fail_shard(bad);
+        auto s = es.solve_ex(4, false, EnumerationSolver::EXCHANGE_LOCAL);
+        CHECK(s.status == LP_BAD_ARG);
+        EnumerationSolver es2(*can);
+        es2.debug_fail_shard(bad);
+        CHECK_THROWS(es2.solve_ex(4, true, EnumerationSolver::EXCHANGE_LOCAL), std::invalid_argument);
+    }
+    // the C entry point with no problem takes part as a failed participant too
+    lp_comm* comms[2] = {nullptr, nullptr};
+    CHECK(lp_comm_create_local(2, comms) == LP_OPTIMAL);
+    int rc0 = 0, rc1 = 0;
+    std::thread t0([&] { rc0 = lp_enum_solve_sharded(comms[0], nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr); });
+    std::thread t1([&] { rc1 = lp_enum_shard_abstain(comms[1], LP_SINGULAR); });
+    t0.join();
+    t1.join();
+    CHECK(rc0 == LP_BAD_ARG && rc1 == LP_SINGULAR);
+    lp_comm_destroy(comms[0]);
+    lp_comm_destroy(comms[1]);
 }
 TEST(Enumeration_WideShape) {
     // 18 rows (more than the 16 of the tuned leaf kernels): C(28,18) = 13.1 M bases on 32-row records and

@@ -646,6 +646,36 @@ def test_feasible_list_grows_and_is_evaluated_from_records(ctx, monkeypatch):
         p.free()
 
 
+def test_dense_form_with_pruned_subtrees(ctx, monkeypatch):
+    """Dense form (rank-indexed scores) on LPs whose breadth-first levels prune whole subtrees as singular
+    (a duplicated column, a zero column): the pruned subsets never get a score written, and with b = 0
+    every feasible score is 0, so any stale 0.0 (or an old score of a previous pass at a shifted offset)
+    in the pooled score buffer would pass the tie rule's `>= star - tol` test.  Full range first, then a
+    sub-range that reuses the same buffer at other offsets; counts, optimum and the tie rule's rank
+    against the oracle."""
+    monkeypatch.setenv("LP_ENUM_LIST_START", "300")
+    for seed, m, n in [(81, 8, 18), (82, 9, 19), (83, 10, 20)]:
+        A, b, c, _ = lpcases.random_lp(seed, m, n)
+        A = A.copy()
+        A[:, 1] = A[:, 0]          # duplicate of the FIRST column: every subset with both is singular,
+        A[:, 3] = 0.0              # and a zero column: ranks 0.. are all pruned at depth 1
+        b = np.zeros_like(b)
+        total = o.binom(n, m)
+        ref = o.enum_range(A, b, c, True, 0, total)
+        assert ref[2][0] > total // 3 and ref[2][2] > 0   # dense territory, with singular subsets
+        p = ctx.enum_problem(A, b, c, True)
+        # a previous pass of ANOTHER shape leaves its scores in the pooled buffer
+        got = p.range(0, total, capi.ENUM_PREFIX)
+        assert got[:3] == ref, (seed, m, n)
+        want = o.enum_first_within(A, b, c, True, 0, total, ref[1])
+        assert p.first_within(0, total, ref[1]) == want
+        for lo, hi in [(total // 7, total - total // 5), (0, total // 3), (total // 2, total)]:
+            ref2 = o.enum_range(A, b, c, True, lo, hi)
+            assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref2, (seed, lo, hi)
+            assert p.first_within(lo, hi, ref2[1]) == o.enum_first_within(A, b, c, True, lo, hi, ref2[1])
+        p.free()
+
+
 def test_fuzz_structured_problems_wide(ctx):
     """Structured data (integers in {-1, 0, 1, 2}: ties, zero pivots, duplicate and zero columns, singular
     prefixes pruning whole subtrees) on the general leaf kernel's shapes — 32-row records and more than 16

@@ -19,7 +19,11 @@ def _run(ctx, A, b, c, basis, maximize, n_orig, trace_cap=1 << 14, max_iter=capi
     rc, st = p.run(max_iter=max_iter, algo=algo)
     out = p.download(trace_cap=min(trace_cap, max(st.pivots, 1)), want_tableau=True)
     p.free()
-    out.update(status=rc, iters=st.pivots)
+    # the algorithm that was asked for is the one that answered (no silent fallback)
+    assert st.fell_back == 0
+    if algo != capi.SIMPLEX_AUTO and rc != capi.SINGULAR:
+        assert st.algo_used == algo, (st.algo_used, algo)
+    out.update(status=rc, iters=st.pivots, algo_used=st.algo_used)
     return out
 
 
@@ -77,6 +81,58 @@ def test_baseline_config_512x1024(ctx, algo):
     xfull = np.zeros(n)
     xfull[g["basis"]] = T[:m, n]
     np.testing.assert_allclose(A @ xfull, b, rtol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_PUBU"])
+def test_baseline_config_512x1024_resident_modes(ctx, monkeypatch, mode):
+    """The chip-resident kernel's placement-dependent forms, forced: participants spread over all
+    XCDs (write-through stores, no shared L2), write-through stores on one XCD, and the A/B form that
+    publishes the candidate column itself instead of its eta column.  Same bits as the oracle."""
+    monkeypatch.setenv(mode, "1")
+    m, n = 512, 1024
+    A, b, c, basis = lpcases.random_lp(0, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
+    g = _run(ctx, A, b, c, basis, True, n - m, algo=capi.SIMPLEX_RESIDENT)
+    _assert_bit_exact(g, r)
+
+
+@pytest.mark.parametrize("seed,m,n", [(41, 768, 1536), (42, 600, 1300), (43, 1024, 2048), (44, 513, 700)])
+def test_resident_rows_beyond_512(ctx, seed, m, n):
+    """512 < m <= 1024: 16 columns per workgroup, up to 1024 threads (one row per thread), workgroups
+    on several XCDs.  AUTO picks the chip-resident algorithm for these shapes too."""
+    A, b, c, basis = lpcases.random_lp(seed, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
+    assert r["status"] == o.OPTIMAL and r["iters"] > 50
+    for algo in (capi.SIMPLEX_RESIDENT, capi.SIMPLEX_AUTO):
+        g = _run(ctx, A, b, c, basis, True, n - m, algo=algo)
+        assert g["algo_used"] == capi.SIMPLEX_RESIDENT
+        _assert_bit_exact(g, r)
+
+
+def test_resident_fallback_is_visible(ctx, monkeypatch):
+    """A hand-off failure (injected: the placement census reports one) must be impossible to miss: with
+    LP_RESIDENT_STRICT (the whole GPU session) the run returns an error; without it the solve is re-run on
+    the look-ahead path, the answer is the same bit for bit, and lp_simplex_stats says which algorithm
+    answered and that it was a fallback.  Nothing of the failed launch reaches the tableau."""
+    A, b, c, basis = lpcases.random_lp(45, 64, 160)
+    r = o.simplex_tableau(A, b, c, basis, True, 96, trace_cap=4096, want_tableau=True)
+    monkeypatch.setenv("LP_RESIDENT_INJECT_FAILURE", "1")
+    p = ctx.simplex_problem(A, b, c, basis, True, 96)
+    with pytest.raises(capi.LPError):
+        p.run(algo=capi.SIMPLEX_RESIDENT)
+    monkeypatch.delenv("LP_RESIDENT_STRICT")
+    for algo in (capi.SIMPLEX_RESIDENT, capi.SIMPLEX_AUTO):
+        p.reset()
+        rc, st = p.run(algo=algo)
+        assert rc == 0 and st.fell_back == 1 and st.algo_used == capi.SIMPLEX_LOOKAHEAD
+        g = p.download(trace_cap=st.pivots, want_tableau=True)
+        g.update(status=rc, iters=st.pivots)
+        _assert_bit_exact(g, r)
+    monkeypatch.delenv("LP_RESIDENT_INJECT_FAILURE")
+    p.reset()
+    rc, st = p.run(algo=capi.SIMPLEX_AUTO)
+    assert rc == 0 and st.fell_back == 0 and st.algo_used == capi.SIMPLEX_RESIDENT and st.launches == 2
+    p.free()
 
 
 @pytest.mark.parametrize("seed,m,n", [(7, 16, 32), (8, 48, 96)])
