@@ -64,13 +64,18 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+PMC_PROFILE = "r03_pmc_traffic.json"
+
+
 def pmc_profile():
-    """profiles/r02_pmc_traffic.json (written by scripts/pmc_to_json.py from two separate rocprofv3
-    --pmc passes, FETCH_SIZE and WRITE_SIZE, of scripts/pmc_traffic.py): HBM bytes per launch of the
-    tableau kernels.  bench.py cannot run rocprofv3 on itself, so the figures are reported only when
-    the file was taken on exactly these kernel sources; otherwise traffic is null."""
+    """profiles/r03_pmc_traffic.json (written by scripts/pmc_to_json.py from separate rocprofv3 --pmc
+    passes: FETCH_SIZE and WRITE_SIZE of scripts/pmc_traffic.py, the VALU and fp64 instruction counters of
+    scripts/pmc_enum.py; plus the rocprofv3 --kernel-trace average of k_simplex_update): HBM bytes per
+    launch of the tableau kernels, executed fp64 operations per enumerated subset.  bench.py cannot run
+    rocprofv3 on itself, so the figures are reported only when the file was taken on exactly these
+    kernel sources; otherwise they are null."""
     try:
-        data = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        data = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
     except Exception:
         return {}
     return data if data.get("kernel_source_hash") == kernel_source_hash() else {}
@@ -103,7 +108,8 @@ def pivot_leg(ctx, args):
             p.reset()
             rc, st = p.run(algo=algo)
             cur = dict(rc=int(rc), solve_ms=st.solve_ms, pivots=st.pivots, launches=st.launches,
-                       kernel_ms=st.update_ms, kernel_launches=st.update_launches)
+                       kernel_ms=st.update_ms, kernel_launches=st.update_launches,
+                       algo_used=int(st.algo_used), fell_back=int(st.fell_back))
             if best is None or cur["solve_ms"] < best["solve_ms"]:
                 best = cur
         return best
@@ -111,7 +117,7 @@ def pivot_leg(ctx, args):
     p.run(algo=args.simplex_algo)                   # warm-up solve
     auto = best_of(args.simplex_algo)
     pivots = max(auto["pivots"], 1)
-    resident = auto["launches"] == 2 and auto["kernel_launches"] == 1   # the chip-resident path ran
+    resident = auto["algo_used"] == capi.SIMPLEX_RESIDENT and not auto["fell_back"]   # the chip-resident path ran
     try:
         look = best_of(capi.SIMPLEX_LOOKAHEAD, 3)
     except capi.LPError:
@@ -152,6 +158,9 @@ def pivot_leg(ctx, args):
     out = {
         "workload": f"simplex m={m} n={n} seed=0 (BASELINE configs[1])",
         "algorithm": "chip-resident tableau (one launch per solve)" if resident else "launch-based",
+        "algo_used": {capi.SIMPLEX_LAUNCH: "launch", capi.SIMPLEX_LOOKAHEAD: "lookahead",
+                      capi.SIMPLEX_RESIDENT: "resident"}.get(auto["algo_used"], str(auto["algo_used"])),
+        "fell_back": bool(auto["fell_back"]),
         "status": auto["rc"], "pivots": int(auto["pivots"]), "launches": int(auto["launches"]),
         "solve_ms": round(auto["solve_ms"], 3),
         "us_per_pivot_whole_solve": round(1e3 * auto["solve_ms"] / pivots, 3),
@@ -167,7 +176,7 @@ def pivot_leg(ctx, args):
     whole = bytes_per_pivot * pivots / (auto["solve_ms"] * 1e-3) / 1e9
     roofline_whole = {
         "what": "whole pivot (pricing + ratio test + update + hand-offs): algorithmic bytes / (solve time / pivots)",
-        "bound": "hbm", "achieved": round(whole, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "handoff-latency" if resident else "hbm", "roofline_it_is_priced_against": "hbm", "achieved": round(whole, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(whole / HBM_PEAK_GBS, 4), "us_per_pivot": out["us_per_pivot_whole_solve"],
     }
     r1 = bytes_per_pivot / (upd1_ms * 1e-3) / 1e9
@@ -178,7 +187,17 @@ def pivot_leg(ctx, args):
         "frac": round(r1 / HBM_PEAK_GBS, 4), "traffic": traffic_of(prof, "k_simplex_update"),
         "launches": 200, "avg_launch_us": round(1e3 * upd1_ms, 3),
         "algorithmic_bytes_per_launch": bytes_per_pivot,
+        "timing": "HIP events around 200 back-to-back launches (this run)",
     }
+    # the same kernel's average under rocprofv3 --kernel-trace (committed with the PMC file, same sources):
+    # the profiler's per-launch duration excludes the back-to-back overlap of the launch ramps
+    try:
+        rp_us = float(prof["kernels"]["k_simplex_update"]["rocprof_avg_launch_us"])
+        roofline_rank1["rocprof_avg_launch_us"] = rp_us
+        roofline_rank1["rocprof_frac"] = round(bytes_per_pivot / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    except Exception:
+        roofline_rank1["rocprof_avg_launch_us"] = None
+        roofline_rank1["rocprof_frac"] = None
     rankj = None
     if updj is not None:
         per_launch_ms, J = updj
@@ -198,41 +217,97 @@ def pivot_leg(ctx, args):
             "kernel": "k_simplex_resident (every pivot of the solve in ONE launch: the tableau stays in the "
                       "registers of ceil(n/32) co-resident workgroups; per pivot one all-to-all hand-off of "
                       "a 32-byte record and a 4 KB column per workgroup through L2)",
-            "bound": "hbm", "achieved": round(k, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "handoff-latency", "roofline_it_is_priced_against": "hbm",
+            "achieved": round(k, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(k / HBM_PEAK_GBS, 4), "traffic": traffic_of(prof, "k_simplex_resident"),
             "launches": 1, "avg_launch_us": round(1e3 * auto["kernel_ms"], 3),
             "pivots_per_launch": int(pivots),
             "algorithmic_bytes_per_launch": bytes_per_pivot * pivots,
             "hbm_bytes_per_launch_by_construction": 2.0 * 8.0 * (m + 1) * (n + 1),
-            "note": "achieved = 16*m*(n+1) B x pivots of the launch / HIP-event time of the launch; the kernel "
+            "note": "achieved/frac = SURVEY 8(d)'s algorithmic rate, 16*m*(n+1) B x pivots of the launch / HIP-event "
+                    "time of the launch, against the HBM peak the north star prices the pivot on; the kernel "
                     "reads the tableau from HBM once and writes it once per SOLVE, so the HBM traffic is "
-                    "1/pivots of the algorithmic bytes and the kernel is bound by the latency of the per-pivot "
-                    "hand-off, not by bandwidth; the HBM-streaming kernels are in roofline_rank1_update / rankj_update",
+                    "1/pivots of the algorithmic bytes and what binds it is the latency of the per-pivot "
+                    "hand-off (bound), not bandwidth; the HBM-streaming kernels are in roofline_rank1_update / rankj_update",
         }
     else:
         roofline = dict(roofline_rank1)
     return out, roofline, roofline_whole, roofline_rank1, rankj
 
 
-def batched_leg(ctx, args):
-    """BASELINE configs[4]: 4096 random LPs of m=128, n=256 (seeds 0..4095), one LP per workgroup."""
+def batched_leg(ctx, args, rank, world, reduce_device):
+    """BASELINE configs[4]: 4096 random LPs of m=128, n=256 (seeds 0..4095), one LP per workgroup,
+    "1 -> 8 GPUs": the LPs are independent, so rank r uploads and solves the LPs
+    [batch*r/N, batch*(r+1)/N) (lp_batched_shard_bounds) and nobody exchanges anything: replicas of the
+    code, no collective in the data path.  The time is the MAX over the ranks of each rank's best
+    device time (HIP events around its launch), the pivots are summed over the ranks.
+
+    Rooflines ("LDS bandwidth if the tableau is chip-resident"): the kernel keeps each
+    LP's condensed tableau (m+1) x (n-m+1) in registers and moves only what crosses threads through LDS.
+      fp64: executed fused multiply-adds of the rank-1 update, 2*(m+1)*(n-m+1) flop per pivot, against
+            the fp64 vector peak (the ratio test's divisions, the eta column and pricing are not counted).
+      lds : the bytes one pivot must move through LDS by construction of the register form - every
+            updating thread reads its share of the eta column (m+1 doubles per column of threads) and one
+            pivot-row entry, the owners store the entering column, the pivot row and the eta column -
+            against 128 B/clk/CU at the 2.4 GHz peak clock."""
     from simplexmethod_amd import capi
+    import ctypes as C
     batch, m, n = args.batch, 128, 256
-    A = np.empty((batch, m, n)); b = np.empty((batch, m)); c = np.empty((batch, n))
-    basis = np.empty((batch, m), dtype=np.int32)
-    for k in range(batch):
-        A[k], b[k], c[k], basis[k] = capi.gen_lp(k, m, n)
-    p = ctx.batched_problem(A, b, c, basis, True, n - m)
-    p.run()
-    ms = min(p.run() for _ in range(3))
-    d = p.download()
-    p.free()
-    piv = int(d["iters"].sum())
+    lo, hi = C.c_int(0), C.c_int(0)
+    capi.load().lp_batched_shard_bounds(batch, rank, world, C.byref(lo), C.byref(hi))
+    lo, hi = lo.value, hi.value
+    mine = hi - lo
+    ms, piv, all_opt = 0.0, 0, True
+    if mine > 0:
+        A = np.empty((mine, m, n)); b = np.empty((mine, m)); c = np.empty((mine, n))
+        basis = np.empty((mine, m), dtype=np.int32)
+        for k in range(mine):
+            A[k], b[k], c[k], basis[k] = capi.gen_lp(lo + k, m, n)
+        p = ctx.batched_problem(A, b, c, basis, True, n - m)
+        p.run()
+        ms = min(p.run() for _ in range(3))
+        d = p.download()
+        p.free()
+        piv = int(d["iters"].sum())
+        all_opt = bool((d["status"] == 0).all())
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([ms], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        q = torch.tensor([piv, 0 if all_opt else 1, mine], dtype=torch.int64, device=reduce_device)
+        dist.all_reduce(q, op=dist.ReduceOp.SUM)
+        piv, all_opt, solved = int(q[0].item()), int(q[1].item()) == 0, int(q[2].item())
+    else:
+        solved = mine
+    if rank != 0:
+        return None
+    cols = n - m + 1                                   # condensed tableau: non-basic columns + right-hand side
+    flops = 2.0 * (m + 1) * cols * piv
+    tf = flops / (ms * 1e-3) / 1e12
+    # LDS bytes per pivot and LP by construction (batched_simplex.hip, register form): thread (column j,
+    # row group g) reads the eta entries of its rows (8 B each, broadcast pairs) and its pivot-row entry;
+    # the entering column, the eta column and the pivot row are each stored once and the scanning wave
+    # reads the entering column, xB and the reduced-cost row once
+    lds_bytes = 8.0 * ((m + 1) * cols + cols) + 8.0 * (3 * (m + 1) + cols) + 8.0 * (2 * (m + 1) + cols)
+    lds_peak_cu = 128.0 * 2.4e9                        # B/s per CU (MI355X_MICROARCH.md: 128 B/clk/CU)
+    cus = 256 * world
+    lds_floor_us = lds_bytes / lds_peak_cu * 1e6       # per pivot of one LP on its CU
+    us_per_pivot_cu = ms * 1e3 * cus / max(piv, 1)
     return {
         "workload": f"{batch} LPs m={m} n={n} seeds 0..{batch - 1} (BASELINE configs[4])",
+        "n_gpus": world, "lps_solved": solved,
+        "parallelism": f"LP-index shards x{world} (lp_batched_shard_bounds): replicas, no exchange",
         "ms": round(ms, 3), "lps_per_s": round(batch / ms * 1e3, 1), "pivots": piv,
-        "all_optimal": bool((d["status"] == 0).all()),
-        "equiv_tableau_GBs": round(16.0 * m * (n + 1) * piv / (ms * 1e-3) / 1e9, 1),
+        "all_optimal": all_opt,
+        "roofline": {"bound": "fp64-vector", "achieved": round(tf, 3), "peak": FP64_VECTOR_PEAK_TF * world,
+                     "unit": "TFLOP/s", "frac": round(tf / (FP64_VECTOR_PEAK_TF * world), 4),
+                     "what": "executed fp64 flops of the rank-1 updates, 2*(m+1)*(n-m+1) per pivot"},
+        "roofline_lds": {"bound": "lds", "lds_bytes_per_pivot_by_construction": lds_bytes,
+                         "floor_us_per_pivot_per_cu": round(lds_floor_us, 3),
+                         "achieved_us_per_pivot_per_cu": round(us_per_pivot_cu, 3),
+                         "frac": round(lds_floor_us / us_per_pivot_cu, 4)},
     }
 
 
@@ -472,6 +547,14 @@ def main():
     shard = my_bounds[1] - my_bounds[0]
 
     winner = ep.vertex(res["rank"], n - m) if res["feasible"] else None
+    # BASELINE configs[4] on every rank (its LP-index shard; replicas, no exchange), while the ranks are
+    # still in step: the legs below run on rank 0 only
+    bl = None if args.no_batched else batched_leg(ctx, args, rank, world, reduce_device)
+    prof_all = pmc_profile()
+    try:
+        fp64_per_subset = float(prof_all["enum_fp64"]["flops_per_subset"]) if (m, n) == (16, 32) else None
+    except Exception:
+        fp64_per_subset = None
     line = None
     if rank == 0:
         line = {
@@ -494,12 +577,14 @@ def main():
                 "kernel_ms_pass1_rank0": round(k_ms, 4),
                 "algorithmic_flops_per_subset": flops_per_subset,
                 "algorithmic_equiv_TFLOPs_no_frac": round(value * flops_per_subset / 1e12, 3),
-                # the shared-prefix kernels EXECUTE ~230 fp64 operations per subset (ISA count of
-                # k_enum_leaves), not the 3,243 an independent solve would need
-                "executed_fp64_ops_per_subset_estimate": 230,
-                "executed_TFLOPs_estimate": round(value * 230 / 1e12, 3),
-                "executed_frac_of_fp64_vector_peak": round(value * 230 / 1e12 / (FP64_VECTOR_PEAK_TF * world), 4),
-                "valu_issue_busy": (pmc_profile().get("enum_valu_issue_busy") if (m, n) == (16, 32) else None),
+                # what the shared-prefix kernels EXECUTE per subset (not the 3,243 flop an independent solve
+                # would need): fp64 instruction counters of one C(32,16) pass (scripts/pmc_enum.py under
+                # rocprofv3 --pmc, scripts/pmc_to_json.py), reported only for the kernel sources they were taken on
+                "executed_fp64_flops_per_subset": fp64_per_subset,
+                "executed_TFLOPs": None if fp64_per_subset is None else round(value * fp64_per_subset / 1e12, 3),
+                "executed_frac_of_fp64_vector_peak": None if fp64_per_subset is None else
+                    round(value * fp64_per_subset / 1e12 / (FP64_VECTOR_PEAK_TF * world), 4),
+                "valu_issue_busy": (prof_all.get("enum_valu_issue_busy") if (m, n) == (16, 32) else None),
                 "mfma": "not used: per-subset row pivoting is data-dependent (DESIGN.md 4.6); no MFMA utilisation to report",
             },
         }
@@ -517,7 +602,7 @@ def main():
         line["enum"]["worst_case_subsets_per_s"] = min(r.get("first_call_subsets_per_s", r["subsets_per_s"])
                                                        for r in line["enum"]["other_inputs"])
     if rank == 0 and not args.no_batched:
-        line["batched"] = batched_leg(ctx, args)
+        line["batched"] = bl
         line["two_phase"] = two_phase_leg(ctx, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_leg(args)

@@ -1,4 +1,4 @@
-"""profiles/r02_pmc_traffic.json from the two PMC passes of scripts/pmc_traffic.py.
+"""profiles/r03_pmc_traffic.json from the two PMC passes of scripts/pmc_traffic.py.
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KB, and on
 gfx950 FETCH_SIZE reads exactly half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM
@@ -41,8 +41,20 @@ for k in KERNELS:
             "FETCH_SIZE_KB": round(fetch[k][0], 2), "WRITE_SIZE_KB": round(write[k][0], 2),
             "launches_sampled": [fetch[k][1], write[k][1]],
             "hbm_bytes_per_launch": round((2.0 * fetch[k][0] + write[k][0]) * 1024.0, 1)}
-if len(sys.argv) > 3:   # optional: VALU issue utilisation of the enumeration leaf kernels (pmc_summary output)
-    out["enum_valu_issue_busy"] = json.load(open(sys.argv[3]))
-path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+if len(sys.argv) > 3:   # optional: VALU issue utilisation (+ fp64 instruction counts) of the enumeration kernels
+    ev = json.load(open(sys.argv[3]))
+    fp = ev.pop("__fp64__", None)
+    out["enum_valu_issue_busy"] = ev
+    if fp is not None:
+        out["enum_fp64"] = fp
+if len(sys.argv) > 4:   # optional: a rocprofv3 --kernel-trace --stats directory; per-launch averages of the tableau kernels
+    fs = sorted(glob.glob(sys.argv[4] + "/**/*kernel_stats.csv", recursive=True))
+    if fs:
+        for r in csv.DictReader(open(fs[-1])):
+            for key, pat in KERNELS.items():
+                if pat in r["Name"] and key in out["kernels"]:
+                    out["kernels"][key]["rocprof_avg_launch_us"] = round(float(r["AverageNs"]) / 1e3, 3)
+                    out["kernels"][key]["rocprof_calls"] = int(r["Calls"])
+path = os.path.join(ROOT, "profiles", bench.PMC_PROFILE)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

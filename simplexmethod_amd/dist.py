@@ -21,6 +21,33 @@ def shard_bounds(total, rank, world):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def batched_shard_bounds(batch, rank, world):
+    """BASELINE configs[4] "1 -> 8 GPUs": participant `rank` solves the LPs [lo, hi) of a batch of
+    independent LPs — the convention of lp_batched_shard_bounds in include/simplexmethod_amd.h
+    (tests/test_dist_cpu.py checks the two agree): contiguous, disjoint, covering, sizes differing by
+    at most one.  There is no collective in the data path: replicas of the code; the caller concatenates
+    the outputs in rank order."""
+    if batch < 0 or world < 1 or not 0 <= rank < world:
+        raise ValueError("batched_shard_bounds: bad (batch, rank, world)")
+    return (batch * rank) // world, (batch * (rank + 1)) // world
+
+
+def batched_solve_sharded(comm, batch, solve_fn):
+    """One-process-per-GPU batched simplex (reference shape: a loop of Solver::solve(),
+    /root/reference/src/main.cpp:111-113, over independent problems).  `solve_fn(lo, hi)` solves the LPs
+    [lo, hi) on this process's device and returns (status[hi-lo], iters[hi-lo]) as int arrays.  No
+    exchange is needed for the answers; the summary below (worst status, total pivots, LPs solved) is
+    the only thing reduced, after the timed region of whoever calls this."""
+    lo, hi = batched_shard_bounds(batch, comm.rank, comm.world)
+    status, iters = solve_fn(lo, hi)
+    status, iters = np.asarray(status, dtype=np.int64), np.asarray(iters, dtype=np.int64)
+    if status.shape != (hi - lo,) or iters.shape != (hi - lo,):
+        raise ValueError("solve_fn must return one status and one pivot count per LP of its shard")
+    bad = int((status != 0).sum())
+    tot = comm.sum_i64(np.array([hi - lo, bad, int(iters.sum())], dtype=np.int64))
+    return dict(bounds=(lo, hi), solved=int(tot[0]), not_optimal=int(tot[1]), pivots=int(tot[2]))
+
+
 def _binom(n, k):
     from math import comb
     return comb(n, k) if 0 <= k <= n else 0

@@ -184,3 +184,94 @@ def test_exchange_single_collective_and_near_tie_branch():
     # nothing feasible anywhere
     out, coll = _run_threads({}, 8, 2)
     assert all(o["feasible"] is False and o["counts"] == [0, 8, 0] for o in out)
+
+
+# ---- BASELINE configs[4] across GPUs: LP-index shards, replicas, no exchange -----------------------------
+
+def test_batched_shard_bounds_cover_and_match_the_c_abi():
+    """Every LP of a batch belongs to exactly one participant, and the Python driver cuts where
+    lp_batched_shard_bounds (what a C++ host binds) cuts."""
+    import ctypes as C
+    from simplexmethod_amd import capi, dist as lpdist
+    lib = capi.load()
+    lo, hi = C.c_int(0), C.c_int(0)
+    for batch in (0, 1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8, 16):
+            seen = np.zeros(batch, dtype=np.int64)
+            sizes = []
+            for r in range(world):
+                a, b = lpdist.batched_shard_bounds(batch, r, world)
+                assert lib.lp_batched_shard_bounds(batch, r, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == (a, b)
+                seen[a:b] += 1
+                sizes.append(b - a)
+            assert (seen == 1).all() and max(sizes) - min(sizes) <= 1
+    assert lib.lp_batched_shard_bounds(8, 2, 2, C.byref(lo), C.byref(hi)) == capi.BAD_ARG
+    assert lib.lp_batched_shard_bounds(8, 0, 0, C.byref(lo), C.byref(hi)) == capi.BAD_ARG
+    with pytest.raises(ValueError):
+        lpdist.batched_shard_bounds(8, 2, 2)
+
+
+def _batched_worker(rank, world, port, batch, m, n, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import pyoracle as o
+    from simplexmethod_amd import dist as lpdist
+    from tests import lpcases
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    objs = {}
+
+    def solve_fn(lo, hi):   # the oracle stands in for the device here: what is under test is the split
+        st, it = [], []
+        for k in range(lo, hi):
+            A, b, c, basis = lpcases.random_lp(k, m, n)
+            r = o.simplex_tableau(A, b, c, basis, True, n - m)
+            st.append(r["status"])
+            it.append(r["iters"])
+            objs[k] = r["obj"]
+        return st, it
+
+    res = lpdist.batched_solve_sharded(lpdist.TorchComm("cpu"), batch, solve_fn)
+    res["objs"] = objs
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batched_simplex_sharded_gloo(world):
+    """world-size-2/3 gloo run of the batched driver: every LP solved exactly once, by the rank the
+    convention names, with the answers of an unsharded run."""
+    import torch.multiprocessing as mp
+    from oracle import pyoracle as o
+    from tests import lpcases
+    batch, m, n = 11, 6, 14
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, batch, m, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len(out) == world
+    ref = {}
+    for k in range(batch):
+        A, b, c, basis = lpcases.random_lp(k, m, n)
+        ref[k] = o.simplex_tableau(A, b, c, basis, True, n - m)
+    owner = {}
+    for r in range(world):
+        res = out[r]
+        assert res["solved"] == batch and res["not_optimal"] == 0
+        assert res["pivots"] == sum(v["iters"] for v in ref.values())
+        lo, hi = res["bounds"]
+        assert sorted(res["objs"]) == list(range(lo, hi))
+        for k, z in res["objs"].items():
+            assert k not in owner
+            owner[k] = r
+            assert z == ref[k]["obj"]
+    assert sorted(owner) == list(range(batch))
