@@ -134,11 +134,11 @@ def pivot_leg(ctx, args):
         buf = (C.c_ulonglong * 16)()
         ctx.lib.lp_debug_simplex_stamps(p.h, 1, buf)
         names = capi.RESIDENT_STAMP_NAMES
-        cyc = [buf[i] / max(st_s.pivots, 1) for i in range(12)]
-        tot = sum(cyc)
+        cyc = [buf[i] / max(st_s.pivots, 1) for i in range(16)]
+        tot = sum(cyc[:5])      # the communication wave's loop = the pivot's critical path
         phases = {"instrumented_solve_ms": round(st_s.solve_ms, 3), "cycles_per_pivot_total": round(tot, 1),
                   "cycles_per_pivot": {k: round(v, 1) for k, v in zip(names, cyc)},
-                  "rank1_update_share_of_pivot": round(cyc[11] / tot, 4) if tot else None}
+                  "hop_share_of_pivot": round(cyc[0] / tot, 4) if tot else None}
     p.reset()
     upd1_ms = min(p.bench_update(0, 0, 200) for _ in range(3))   # ms per rank-1 update launch
     try:   # rank-J update alone: 200 back-to-back launches between two events

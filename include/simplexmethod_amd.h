@@ -91,7 +91,7 @@ enum {
                                       one rank-J update pass over the tableau            */
     LP_SIMPLEX_ALGO_RESIDENT = 3   /* one launch per solve: the tableau stays in the registers of
                                       co-resident workgroups, one per CU (32 columns each for
-                                      m <= 512, 16 columns each for 512 < m <= 1024; at most 256
+                                      m <= 512, 16 columns each for 512 < m <= 960; at most 256
                                       workgroups, i.e. n <= 8192 resp. n <= 4096), one all-to-all
                                       hand-off per pivot; AUTO's choice when the shape fits.  A
                                       hand-off that times out (the workgroups never became

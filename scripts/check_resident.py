@@ -87,10 +87,11 @@ buf = (C.c_ulonglong * (16 * G))()
 ctx.lib.lp_debug_simplex_stamps(p.h, G, buf)
 acc = np.array(buf[:16 * G], dtype=np.float64).reshape(G, 16) / st.pivots
 names = capi.RESIDENT_STAMP_NAMES
-print("stamped run: %.3f ms; cycles per pivot (mean over %d pivots), workgroup 0: total %d" % (st.solve_ms, st.pivots, acc[0, :12].sum()))
-for i in range(12):
-    print("  %-72s %6d   (min %5d  max %5d over workgroups)" % (names[i], acc[0, i], acc[:, i].min(), acc[:, i].max()))
-print("record wait per workgroup:", " ".join("%d" % v for v in acc[:, 1]))
+print("stamped run: %.3f ms; cycles per pivot (mean over %d pivots), workgroup 0: communication wave %d, row wave 0 %d" %
+      (st.solve_ms, st.pivots, acc[0, :5].sum(), acc[0, 6:15].sum()))
+for i in range(16):
+    print("  %-80s %6d   (min %5d  max %5d over workgroups)" % (names[i], acc[0, i], acc[:, i].min(), acc[:, i].max()))
+print("record wait per workgroup:", " ".join("%d" % v for v in acc[:, 0]))
 p.free()
 ctx.close()
 print("ALL OK" if ok else "MISMATCH")

@@ -39,15 +39,48 @@ def hipcc_path():
 
 
 def build_hip(force=False, verbose=False):
+    """Every csrc/*.hip -> _build/obj/<name>.o (only the stale ones, a few at a time), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OUT, exist_ok=True)
+    obj_dir = os.path.join(OUT, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = _sources(CSRC, (".hip",))
-    deps = srcs + _sources(CSRC, (".hpp",)) + _sources(INCLUDE, (".h",))
-    if not force and _newer(HIP_LIB, deps):
-        return HIP_LIB
+    hdrs = _sources(CSRC, (".hpp",)) + _sources(INCLUDE, (".h",))
     extra = os.environ.get("LP_HIPCC_EXTRA", "").split()
-    cmd = [hipcc_path()] + HIPCC_FLAGS + extra + ["-o", HIP_LIB] + srcs + ["-ldl", "-pthread"]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    # the flags are part of an object's identity (LP_HIPCC_EXTRA builds must not reuse plain objects)
+    stamp = os.path.join(obj_dir, "flags.txt")
+    flag_text = " ".join(flags + extra)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+    objs, todo = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        if force or not _newer(obj, [src] + hdrs):
+            todo.append((src, obj))
+    for stale in set(_sources(obj_dir, (".o",))) - set(objs):
+        os.remove(stale)
+    if not todo and _newer(HIP_LIB, objs):
+        return HIP_LIB
+    hipcc = hipcc_path()
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc] + flags + extra + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    workers = max(1, min(len(todo), int(os.environ.get("LP_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1)))
+    if todo:
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(compile_one, todo))
+    with open(stamp, "w") as f:
+        f.write(flag_text)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl", "-pthread"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return HIP_LIB
 

@@ -92,13 +92,18 @@ SIGNATURES = {
 }
 
 # phases of the chip-resident kernel's diagnostic instantiation (lp_debug_simplex_stamps after a
-# chip-resident run: cycle sums of wave 0 of each workgroup, in this order)
+# chip-resident run: cycle sums per workgroup, in this order): slots 0-5 the communication wave
+# (polls, decides, finishes the ratio test, publishes), slots 6-15 row wave 0
 RESIDENT_STAMP_NAMES = [
-    "loop", "poll_records", "decide", "decision_barrier",
-    "read_decision_pivot_row_to_lds_request_column_two_quotients", "pivot_row_barrier",
-    "reduced_costs_and_next_pricing", "column_wait_eta_entry",
-    "candidate_ratio_stage1", "ratio_barrier", "wave_W2_only_ratio_stage2_and_record",
-    "rank1_update_and_eta_column_publication"]
+    "comm: poll_records (the hop)", "comm: decide_and_decision_block",
+    "comm: waits while the rows read the decision and stage the pivot row",
+    "comm: waits for the rows' pricing + ratio slices, then ratio stage 2 + record",
+    "comm: loop", "comm: commit",
+    "rows: wait for the decision (publish -> hop -> decide)",
+    "rows: read_decision_request_column_pivot_row_to_lds_two_quotients", "rows: pivot_row_barrier",
+    "rows: reduced_costs_and_next_pricing", "rows: column_wait_eta_entry",
+    "rows: candidate_ratio_slice", "rows: ratio_barrier",
+    "rows: rank1_update_and_eta_column_publication", "rows: loop", "rows: commit"]
 
 _lib = None
 

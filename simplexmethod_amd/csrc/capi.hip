@@ -378,7 +378,7 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     switch (algo) {
         case LP_SIMPLEX_ALGO_RESIDENT:
             if (p->res.G < 1)
-                LP_FAIL(ctx, LP_BAD_ARG, "chip-resident simplex needs m <= 1024 and ceil(n / columns per workgroup) <= 256 workgroups");
+                LP_FAIL(ctx, LP_BAD_ARG, "chip-resident simplex needs m <= 960 and ceil(n / columns per workgroup) <= 256 workgroups");
             rc = lp_simplex_run_resident(p, eps, max_iter, stats_out);
             break;
         case LP_SIMPLEX_ALGO_LAUNCH:
@@ -593,7 +593,7 @@ int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long
         const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64);
         LP_HIP(ctx, hipMalloc(&p->look.stamps, bytes));
         LP_HIP(ctx, hipMemset(p->look.stamps, 0, bytes));
-        const size_t rbytes = sizeof(unsigned long long) * 16 * 256;   // the resident kernel: 16 per-phase cycle sums per workgroup
+        const size_t rbytes = sizeof(unsigned long long) * 16 * 256 * 2;   // the resident kernel: 16 per-phase cycle sums per workgroup + 16 progress markers
         LP_HIP(ctx, hipMalloc(&p->res.stamps, rbytes));
         LP_HIP(ctx, hipMemset(p->res.stamps, 0, rbytes));
         return LP_OPTIMAL;

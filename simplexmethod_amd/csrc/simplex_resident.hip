@@ -5,20 +5,27 @@
 // same bits in every tableau element (each element takes the same fma per pivot), but the tableau
 // never moves: G co-resident workgroups hold CPT columns each in REGISTERS (thread i = tableau
 // row i; the xB column is replicated in every workgroup) for the whole solve, one launch per solve.
-//   m <= 512 : 32 columns per workgroup, up to 512 threads (a 512 x 1024 tableau = 32 workgroups x
+//   m <= 512 : 32 columns per workgroup, up to 512 row threads (a 512 x 1024 tableau = 32 workgroups x
 //              131 KB of registers = one XCD of the MI355X)
-//   m <= 1024: 16 columns per workgroup, up to 1024 threads
+//   m <= 960 : 16 columns per workgroup, up to 960 row threads
+// Every workgroup has ONE MORE WAVE, the communication wave, which owns no rows: it polls the other
+// workgroups' records, takes the decision, finishes the ratio test and publishes.  A wave that also
+// updates rows cannot poll while it updates, and the hop between "my record is out" and "I know
+// everybody's" costs 1000 cycles when a wave does nothing else (scripts/ubench_hop_pure.hip) against
+// 3000 when the polling wave first has its 64 rows to update (the previous form of this kernel).
 //
 // One pivot = ONE all-to-all hop between the workgroups:
 //   publish  every workgroup prices its own columns (Dantzig chain summary: extreme M_k, its first
 //            index, "M_k beats everything of mine in front of it by more than eps"), runs the ratio
-//            test (:181-192) on ITS candidate column speculatively, and publishes ONE 32-byte record
-//            {M_k, column, verdict, leaving row, u_r}; behind it, off the critical path, the eta
-//            column -u_i/u_r of its candidate (:201), one value per thread;
-//   consume  wave 0 of every workgroup reads all G records and replays the reference's scan over
-//            them — identical inputs, identical decision everywhere, no leader; every thread then
-//            reads its entry of the winner's eta column and applies the rank-1 update to its own
-//            registers (its part of the pivot row is local).
+//            test (:181-192) on ITS candidate column speculatively — every row wave its 64 rows, the
+//            communication wave the combination — and publishes ONE 32-byte record {M_k, column,
+//            verdict, leaving row, u_r}; behind it, off the critical path, the row threads publish the
+//            eta column -u_i/u_r of the candidate (:201), one value per thread;
+//   consume  the communication wave of every workgroup reads all G records (G <= 32: one 64-lane
+//            load, the next one already in flight) and replays the reference's scan over them —
+//            identical inputs, identical decision everywhere, no leader; every row thread then reads
+//            its entry of the winner's eta column and applies the rank-1 update to its own registers
+//            (its part of the pivot row is local).
 //   Near-ties (the hysteresis of :157 / :168 cannot be decided from the summaries) take an exact
 //   slow path: the scan is replayed over all n published reduced costs and the owner of the
 //   entering column publishes it in a second hop.
@@ -28,7 +35,7 @@
 // loads that bypass the reader's L1; a reader spins until every tag equals the pivot's epoch, so
 // no flags, fences or drains are needed.  Two parities of every slot suffice: a workgroup publishes
 // epoch p+2 only after consuming everyone's p+1.  Stores are write-through (sc1) unless a census at
-// kernel start shows all participants on one XCD, whose shared L2 then serves plain stores (2x
+// kernel start shows all participants on one XCD, whose shared L2 then serves plain stores (3x
 // faster hop; placement is observed, never assumed).  Every spin is bounded: on a timeout the
 // failing workgroup raises a chip-wide abort word and NOTHING is written back — the tableau goes
 // home only behind one last hop in which every workgroup has seen every other one finish — and the
@@ -117,14 +124,14 @@ struct Shared {
     double* prow;    // CPT + 8   : this workgroup's part of the pivot row (+ xB_r at CPT)
     double* ratio;   // mpad      : ratio-test values of the staged candidate (near-tie replay)
     double* u;       // mpad      : the staged candidate column
-    lpdev::BlockSelScratch* sc;
+    struct SelScratch* sel;
     Ctl* ctl;
-    v4i* pub;        // {epoch, u_r.lo, epoch, u_r.hi} of my candidate, from the wave that finishes the ratio test
+    v4i* pub;        // {epoch, u_r.lo, epoch, u_r.hi} of my candidate, from the communication wave
     int* basis;      // mpad      : N by position (every workgroup keeps its own copy)
 };
 
 __host__ __device__ inline size_t resident_lds_bytes(int mpad, int cpt) {
-    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + sizeof(lpdev::BlockSelScratch) + sizeof(Ctl) + 16 +
+    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + 512 /* SelScratch */ + sizeof(Ctl) + 16 +
            sizeof(int) * (size_t)mpad;
 }
 
@@ -137,15 +144,26 @@ struct Comm {   // buffer descriptor and byte offsets of the hand-off areas (all
 // reference's `<` / `>` scans, exactly like the sentinel)
 __device__ __forceinline__ double nan_to(double v, double sentinel) { return (v == v) ? v : sentinel; }
 
-// CPT columns per workgroup, at most NT threads (the launch uses mpad = m rounded up to 64).
+struct SelScratch {   // LDS: ratio-test slice summaries (one per row wave) and the pricing summary of the candidate
+    unsigned long long M[16];   // sortable key of the slice's smallest ratio
+    double U[16];               // the candidate column's entry at the slice's first minimum
+    int ok[16];                 // "the slice's minimum beats everything of the slice in front of it by more than eps"
+    int J[16];                  // row of the slice's first minimum (INT_MAX: nothing eligible)
+    unsigned long long pM;      // sortable key of M_k, the extreme reduced cost of my columns
+    int pJ, pOk;                // its first column (local index, -1: none eligible); verdict on my columns in front of it
+};
+static_assert(sizeof(SelScratch) <= 512 && sizeof(SelScratch) % 16 == 0, "resident_lds_bytes reserves 512 bytes, 16-byte aligned");
+
+// CPT columns per workgroup; NT = upper bound of the row threads (the launch uses mpad = m rounded up to
+// 64 row threads PLUS ONE COMMUNICATION WAVE: blockDim = mpad + 64).
 // PUBL: the published column is the eta column -u_i/u_r (the consumers' division comes off the
 //       critical path); !PUBL (A/B, LP_RESIDENT_PUBU=1): u_i itself, stored before the ratio test.
 template <int CPT, int NT, bool STAMPS, bool PUBL>
-__global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentDev rd) {
+__global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, ResidentDev rd) {
     static_assert(CPT == 32 || CPT == 16, "the slab is two vectors of 16 or 8 doubles");
     constexpr int HALF = CPT / 2;
-    constexpr int NWMAX = NT / 64;          // 8 or 16 waves
-    constexpr int KREPLAY = 4;              // entries per lane and tile of the near-tie replay (256-row tiles)
+    constexpr int NWMAX = NT <= 512 ? 8 : 16;   // slices of the ratio test (a power of two >= row waves)
+    constexpr int KREPLAY = 4;                  // entries per lane and tile of the near-tie replay (256-row tiles)
     typedef double vslab __attribute__((ext_vector_type(HALF)));
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x % (unsigned)rd.stride) return;
@@ -155,25 +173,27 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
     SimplexState* st = d.state;
     if (st->status != kRunning) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    // (wave-uniform by construction; telling the compiler makes every `wave == ...` a scalar branch
+    // (wave-uniform by construction; telling the compiler makes every role test a scalar branch
     // instead of an exec-mask region)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = d.m, n = d.n, ld = d.ld;
     const int mpad = rd.mpad;
-    const int W2 = (mpad > 64) ? 1 : 0;   // the wave that finishes the ratio test and publishes the record
+    const int nrw = mpad >> 6;                 // row waves 0 .. nrw-1 (thread i = tableau row i)
+    const bool is_comm = wave == nrw;          // the last wave: polls, decides, finishes the ratio test, publishes
     const bool rowok = tid < m;
     const int col0 = k * CPT;
     const bool maximize = d.maximize != 0;
     const double eps = st->eps;
     const int max_iter = st->max_iter;
     const unsigned long long kNegInf = lpdev::f64_sort_key(-INFINITY);
+    const unsigned long long kPosInf = lpdev::f64_sort_key(INFINITY);
 
     Shared sh;
     sh.prow = smem;
     sh.ratio = sh.prow + CPT + 8;
     sh.u = sh.ratio + mpad;
-    sh.sc = reinterpret_cast<lpdev::BlockSelScratch*>(sh.u + mpad);
-    sh.ctl = reinterpret_cast<Ctl*>(sh.sc + 1);
+    sh.sel = reinterpret_cast<SelScratch*>(sh.u + mpad);
+    sh.ctl = reinterpret_cast<Ctl*>(sh.sel + 1);
     sh.pub = reinterpret_cast<v4i*>(sh.ctl + 1);
     sh.basis = reinterpret_cast<int*>(sh.pub + 1);
 
@@ -197,22 +217,23 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         }
     }
     double xb = rowok ? d.T[(size_t)tid * ld + n] : 0.0;   // replica of column n
-    // reduced costs of this workgroup's columns: lane l of EVERY wave holds column col0 + l
+    // reduced costs of this workgroup's columns: lane l of EVERY row wave holds column col0 + l
     const int mycol = col0 + lane;
     const bool colok = lane < CPT && mycol < n;
     bool nbl = colok && d.nonbasic[colok ? mycol : 0] != 0;
     double dl = colok ? d.T[(size_t)m * ld + mycol] : 0.0;
     double obj = d.T[(size_t)m * ld + n];
-    for (int i = tid; i < m; i += mpad) sh.basis[i] = d.basis[i];
+    for (int i = tid; i < m; i += mpad + 64) sh.basis[i] = d.basis[i];
     int it = st->iters;
     int status = (it >= max_iter) ? LP_ITER_LIMIT : kRunning;   // SimplexSolver.h:429,:450
 
     // ---- placement census: are all participants on one XCD (then plain stores reach the shared L2)?
-    {
+    if (is_comm) {
+        __builtin_amdgcn_s_setprio(3);   // the pivot's critical path runs through this wave: it wins issue arbitration on its SIMD
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 15u;
-        if (tid == 0) {
+        if (lane == 0) {
             v4i g = {1, (int)xcc, 1, 0};
             st16(g, cm.r, cm.census + (unsigned)k * 16u, false);
             sh.ctl->fail = 0;
@@ -220,37 +241,36 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
             v4i z = {0, 0, 0, 0};
             *sh.pub = z;
         }
-        if (wave == 0) {
-            Spin spin;
-            bool same = true, failed = false;
-            for (;;) {
-                bool ok = true;
-                same = true;
-                for (int q = lane; q < G; q += 64) {
-                    const v4i g = ld16(cm.r, cm.census + (unsigned)q * 16u);
-                    ok &= g_fresh(g, 1u);
-                    same &= g.y == (int)xcc;
-                }
-                if (__all(ok)) break;
-                if (spin.expired(cm.r, cm.abort)) {
-                    failed = true;
-                    break;
-                }
+        Spin spin;
+        bool same = true, failed = false;
+        for (;;) {
+            bool ok = true;
+            same = true;
+            for (int q = lane; q < G; q += 64) {
+                const v4i g = ld16(cm.r, cm.census + (unsigned)q * 16u);
+                ok &= g_fresh(g, 1u);
+                same &= g.y == (int)xcc;
             }
-            const bool all_same = __all(same);   // (a vote inside `if (lane == 0)` would see lane 0 only)
-            if (lane == 0) {
-                sh.ctl->plain = (all_same && !(rd.flags & 1)) ? 1 : 0;
-                if (failed || (rd.flags & 2)) sh.ctl->fail = 1;   // code 1: census (flag bit 1: injected by the tests)
+            if (__all(ok)) break;
+            if (spin.expired(cm.r, cm.abort)) {
+                failed = true;
+                break;
             }
         }
-        __syncthreads();
+        const bool all_same = __all(same);   // (a vote inside `if (lane == 0)` would see lane 0 only)
+        if (STAMPS && rd.stamps && lane == 0) rd.stamps[16 * 256 + (size_t)k * 16 + 15] = 1000u + xcc * 10u + (all_same ? 1u : 0u);
+        if (lane == 0) {
+            sh.ctl->plain = (all_same && !(rd.flags & 1)) ? 1 : 0;
+            if (failed || (rd.flags & 2)) sh.ctl->fail = 1;   // code 1: census (flag bit 1: injected by the tests)
+        }
     }
+    __syncthreads();
     const bool plain = sh.ctl->plain != 0;
     if (sh.ctl->fail) status = kResidentFailed;
 
-    // Diagnostic build only (STAMPS): cycles of every phase of wave 0, summed over the solve in
-    // registers and stored once at the end (a store per stamp would sit in front of every later
-    // vmcnt wait and distort what it measures).
+    // Diagnostic build only (STAMPS): cycles of every phase of the communication wave (slots 0-5) and of
+    // row wave 0 (slots 6-15), summed over the solve in registers and stored once at the end (a store per
+    // stamp would sit in front of every later vmcnt wait and distort what it measures).
     unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = STAMPS ? __builtin_readcyclecounter() : 0;
 #define RS_STAMP(s)                                                          \
@@ -259,32 +279,20 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
             const unsigned long long now_ = __builtin_readcyclecounter();    \
             acc[(s)] += now_ - tprev;                                        \
             tprev = now_;                                                    \
+            /* progress marker of this wave (read by the host after a timed-out run only) */ \
+            if (rd.stamps && lane == 0) rd.stamps[16 * 256 + (size_t)k * 16 + wave] = (unsigned long long)ep * 100u + (s); \
         }                                                                    \
     } while (0)
+#define RS_STAMP_C(s) do { if (is_comm) RS_STAMP(s); } while (0)
+#define RS_STAMP_R(s) do { if (!is_comm) RS_STAMP(s); } while (0)
 
     unsigned ep = 0, par = 0, slot = 0;
     double pv = 0.0;
     unsigned long long pkey = 0, mkey = 0, hit = 0;
     int jl = -1;
     double lpub = 0.0;    // my entry of the eta column of my own candidate (what I published)
-    // records per lane of the polling wave (blocked: lane order = column order)
-    const int R = (G + 63) >> 6;
-    const int q0 = lane * R;
-    v4i pfa = {0, 0, 0, 0}, pfb = {0, 0, 0, 0};
-    bool pf = false;
-    // wave 0 issues its first poll of the records behind its rank-1 update: by then they are mostly
-    // out, and the round trip of the poll runs under the rest of the phase
-#define RS_PREFETCH()                                                                     \
-    do {                                                                                  \
-        if (wave == 0 && q0 < G) {                                                        \
-            const unsigned base = cm.rec + (par * (unsigned)G + (unsigned)q0) * 32u;      \
-            pfa = ld16(cm.r, base);                                                       \
-            pfb = ld16(cm.r, base + 16);                                                  \
-            pf = true;                                                                    \
-        }                                                                                 \
-    } while (0)
 
-    // pricing summary of my columns (:152-174; minimisation scans -d with the same rule).  Every
+    // pricing summary of my columns (:152-174; minimisation scans -d with the same rule).  Every row
     // wave computes it from its own replica (lane l = column l): no barrier, no LDS.
 #define RS_PRICE()                                                                 \
     do {                                                                           \
@@ -295,148 +303,249 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         jl = hit ? (int)__builtin_ctzll(hit) : -1;                                 \
     } while (0)
 
-    // Candidate (column values UP for the rows, xB values XBV): first half of the ratio test
-    // (:181-192; every wave leaves its slice summary in LDS), a barrier, then wave W2 finishes the
-    // ratio test and publishes the record {M_k, column, verdict on my columns in front of it, leaving
-    // row, u_r}; through LDS it hands u_r to the other waves, which publish the eta column behind
-    // their part of the rank-1 update (RS_PUBLISH_COLUMN).
-#define RS_PUBLISH(UP, XBV)                                                                          \
+    // Candidate (column values UP for the rows, xB values XBV).  Row waves: first half of the ratio test
+    // (:181-192; every wave leaves the summary of its 64 rows in LDS), wave 0 adds the pricing summary.
+    // A barrier.  The communication wave finishes the ratio test and publishes the record {M_k, column,
+    // verdict on my columns in front of it, leaving row, u_r}; through LDS it hands u_r to the row waves,
+    // which publish the eta column behind their part of the rank-1 update (RS_PUBLISH_COLUMN).
+#define RS_CANDIDATE(UP, XBV)                                                                        \
     do {                                                                                             \
         ++ep;                                                                                        \
         par = ep & 1u;                                                                               \
         slot = par * (unsigned)G + (unsigned)k;                                                      \
-        if (jl >= 0) {                                                                               \
-            if (!PUBL && rowok) st16(g_pack(ep, (UP)), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
-            const double ratio_ = (rowok && (UP) > eps) ? nan_to((XBV) / (UP), INFINITY) : INFINITY;   /* :185-186 */ \
-            sh.ratio[tid] = ratio_;                                                                  \
-            sh.u[tid] = (UP);                                                                        \
-            lpdev::block_select_stage1_n<false>(ratio_, eps, sh.sc);                                 \
+        if (!is_comm) {                                                                              \
+            if (jl >= 0) {                                                                           \
+                if (!PUBL && rowok) st16(g_pack(ep, (UP)), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
+                const double ratio_ = (rowok && (UP) > eps) ? nan_to((XBV) / (UP), INFINITY) : INFINITY;   /* :185-186 */ \
+                sh.ratio[tid] = ratio_;                                                              \
+                sh.u[tid] = (UP);                                                                    \
+                unsigned long long rhit_;                                                            \
+                const unsigned long long rk_ = lpdev::wave_ext_key_n<false, 64>(lpdev::f64_sort_key(ratio_), &rhit_); \
+                const bool any_ = rk_ != kPosInf;                                                    \
+                const int L_ = any_ ? (int)__builtin_ctzll(rhit_) : 0;                               \
+                const unsigned long long near_ =                                                     \
+                    __ballot(lane < L_ && !lpdev::beats<false>(lpdev::f64_from_key(rk_), ratio_, eps)); \
+                const double uL_ = lpdev::wave_bcast_f64((UP), L_);                                  \
+                if (lane == 0) {                                                                     \
+                    sh.sel->M[wave] = rk_;                                                           \
+                    sh.sel->U[wave] = uL_;                                                           \
+                    sh.sel->ok[wave] = (any_ && near_ == 0ULL) ? 1 : 0;                              \
+                    sh.sel->J[wave] = any_ ? wave * 64 + L_ : INT_MAX;                               \
+                }                                                                                    \
+            }                                                                                        \
+            if (wave == 0) {                                                                         \
+                /* does my maximum beat every reduced cost of mine in front of it by more than eps? */ \
+                const double Mk_ = hit ? lpdev::f64_from_key(mkey) : -INFINITY;                      \
+                const bool okp_ = hit && __ballot(lane < jl && !(Mk_ > pv + eps)) == 0ULL;           \
+                if (lane == 0) {                                                                     \
+                    sh.sel->pM = hit ? mkey : kNegInf;                                               \
+                    sh.sel->pJ = jl;                                                                 \
+                    sh.sel->pOk = okp_ ? 1 : 0;                                                      \
+                }                                                                                    \
+            }                                                                                        \
         }                                                                                            \
-        RS_STAMP(8);                                                                                 \
+        RS_STAMP_R(11);                                                                              \
+        RS_STAMP_C(2);                                                                               \
         __syncthreads();                                                                             \
-        RS_STAMP(9);                                                                                 \
-        if (wave == W2) {                                                                            \
-            /* does my maximum beat every reduced cost of mine in front of it by more than eps? */   \
-            const double Mk_ = hit ? lpdev::f64_from_key(mkey) : -INFINITY;                          \
-            const unsigned okp = (hit && __ballot(lane < jl && !(Mk_ > pv + eps)) == 0ULL) ? 0x8000u : 0u; \
+        RS_STAMP_R(12);                                                                              \
+        if (is_comm) {                                                                               \
+            const int pJ_ = sh.sel->pJ;                                                              \
+            const int pOk_ = sh.sel->pOk;                                                            \
+            const unsigned long long pM_ = sh.sel->pM;                                               \
             int rk = -1;                                                                             \
             double urk = 0.0;                                                                        \
-            if (jl >= 0) {                                                                           \
-                rk = lpdev::block_select_stage2_n<false, NWMAX, KREPLAY>(sh.ratio, m, eps, sh.sc);   \
-                urk = (rk >= 0) ? sh.u[rk] : 0.0;                                                    \
+            if (pJ_ >= 0) {                                                                          \
+                const bool has_ = lane < nrw;                                                        \
+                const unsigned long long Ml_ = has_ ? sh.sel->M[lane & 15] : kPosInf;                \
+                const int okl_ = has_ ? sh.sel->ok[lane & 15] : 0;                                   \
+                const int Jl_ = has_ ? sh.sel->J[lane & 15] : INT_MAX;                               \
+                const double Ul_ = has_ ? sh.sel->U[lane & 15] : 0.0;                                \
+                unsigned long long h2_;                                                              \
+                const unsigned long long M2_ = lpdev::wave_ext_key_n<false, NWMAX>(Ml_, &h2_);       \
+                if (M2_ != kPosInf) {                                                                \
+                    const int W_ = (int)__builtin_ctzll(h2_);   /* first slice attaining the minimum (row order) */ \
+                    const int jM_ = __builtin_amdgcn_readlane(Jl_, W_);                              \
+                    const int okW_ = __builtin_amdgcn_readlane(okl_, W_);                            \
+                    const double uW_ = lpdev::wave_bcast_f64(Ul_, W_);                               \
+                    const unsigned long long near2_ = __ballot(                                      \
+                        lane < W_ && !lpdev::beats<false>(lpdev::f64_from_key(M2_), lpdev::f64_from_key(Ml_), eps)); \
+                    if (okW_ && near2_ == 0ULL) {                                                    \
+                        rk = jM_;                                                                    \
+                        urk = uW_;                                                                   \
+                    } else {   /* near-tie: exact replay over the LDS copy of the ratios */          \
+                        double best_;                                                                \
+                        auto load_ = [&](int j, bool& ok) {                                          \
+                            ok = true;                                                               \
+                            return sh.ratio[j];                                                      \
+                        };                                                                           \
+                        rk = lpdev::wave_chain_select<false, KREPLAY>(m, eps, best_, load_);         \
+                        urk = (rk >= 0) ? sh.u[rk] : 0.0;                                            \
+                    }                                                                                \
+                }                                                                                    \
             }                                                                                        \
             if (lane < 2) {                                                                          \
-                const v4i g = lane == 0 ? r_pack(ep, jl >= 0 ? (unsigned)(col0 + jl) : kNoColumn,    \
-                                                 okp | (unsigned)(rk + 1), Mk_)                      \
+                const v4i g = lane == 0 ? r_pack(ep, pJ_ >= 0 ? (unsigned)(col0 + pJ_) : kNoColumn,  \
+                                                 (pOk_ ? 0x8000u : 0u) | (unsigned)(rk + 1), lpdev::f64_from_key(pM_)) \
                                         : r_pack(ep, 0u, 0u, urk);                                   \
                 st16(g, cm.r, cm.rec + slot * 32u + (unsigned)lane * 16u, plain);                    \
             }                                                                                        \
-            if (PUBL && lane == 0) *sh.pub = g_pack(ep, urk);                                        \
+            if (rd.flags & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* experiment: drain the record store */ \
+            if (PUBL && lane == 0) *sh.pub = g_pack(ep, urk);   /* read behind RS_PUBLISH_COLUMN's barrier */ \
+            RS_STAMP(3);                                                                             \
         }                                                                                            \
     } while (0)
 
-    // eta column of my candidate, one entry per thread: F(i,r) = -u_i/u_r (:201) — exactly the value
-    // the consumers would compute from u_i and the record's u_r, computed once here, off their path
+    // eta column of my candidate, one entry per row thread: F(i,r) = -u_i/u_r (:201) — exactly the value
+    // the consumers would compute from u_i and the record's u_r, computed once here, off their path.
+    // u_r comes from the communication wave through LDS behind a workgroup barrier (every wave executes
+    // this macro).  NOT a spin on the LDS word: the communication wave is the youngest wave of its SIMD,
+    // and older waves spinning there starved it — its record came out 200 ms late or never.
 #define RS_PUBLISH_COLUMN(UP)                                                                        \
     do {                                                                                             \
-        if (PUBL && jl >= 0) {                                                                       \
-            v4i pg_ = lds_granules(sh.pub);                                                          \
-            while (!g_fresh(pg_, ep)) pg_ = lds_granules(sh.pub);   /* wave W2 is at most one phase behind */ \
-            lpub = -(UP) / g_f64(pg_);                                                               \
-            if (rowok) st16(g_pack(ep, lpub), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
+        if (PUBL) {                                                                                  \
+            __syncthreads();                                                                         \
+            if (!is_comm && jl >= 0) {                                                               \
+                lpub = -(UP) / g_f64(*sh.pub);                                                       \
+                if (rowok) st16(g_pack(ep, lpub), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
+            }                                                                                        \
         }                                                                                            \
     } while (0)
 
     double up = 0.0;
     if (status == kRunning) {   // prologue: candidate of the initial tableau
-        RS_PRICE();
-        if (jl >= 0) up = RS_SLAB_GET(jl);
-        RS_PUBLISH(up, xb);
+        if (!is_comm) {
+            RS_PRICE();
+            if (jl >= 0) up = RS_SLAB_GET(jl);
+        }
+        RS_CANDIDATE(up, xb);
         RS_PUBLISH_COLUMN(up);
-        RS_PREFETCH();
     }
     while (status == kRunning) {
-        RS_STAMP(0);
-        // ================= consume: everyone's records, one decision ============================
-        if (wave == 0) {
-            double Ml = -INFINITY, Mfront = -INFINITY;
-            unsigned el = kNoColumn, miscl = 0;
-            int ql = -1;
-            double ul = 0.0;
-            Spin spin;
-            bool failed = false;
-            for (;;) {
-                bool ok = true;
-                Ml = -INFINITY; Mfront = -INFINITY; el = kNoColumn; miscl = 0; ql = -1; ul = 0.0;
-                for (int t = 0; t < R; ++t) {
-                    const int q = q0 + t;
-                    if (q >= G) break;
-                    const unsigned base = cm.rec + (par * (unsigned)G + (unsigned)q) * 32u;
-                    v4i a, b;
-                    if (t == 0 && pf) {
-                        a = pfa;
-                        b = pfb;
-                    } else {
-                        a = ld16(cm.r, base);
-                        b = ld16(cm.r, base + 16);
-                    }
-                    ok &= r_fresh(a, ep) && r_fresh(b, ep);
-                    const double Mq = g_f64(a);
-                    const unsigned eq = (unsigned)a.x & 0xFFFFu;
-                    if (eq < kCommit && Mq > Ml) {           // strictly greater: ties keep the earlier column
-                        Mfront = Ml;                         // the extreme of this lane's records in front of it
-                        Ml = Mq;
-                        el = eq;
-                        miscl = (unsigned)a.z & 0xFFFFu;
-                        ul = g_f64(b);
-                        ql = q;
-                    }
-                }
-                pf = false;
-                if (__all(ok)) break;
-                if (spin.expired(cm.r, cm.abort)) {
-                    failed = true;
-                    const unsigned long long bad = __ballot(!ok);
-                    if (lane == 0) sh.ctl->pad0 = bad ? (int)__builtin_ctzll(bad) * R : -1;   // first stale record
-                    break;
-                }
-            }
-            RS_STAMP(1);
-            unsigned long long whit;
-            const unsigned long long Mk = lpdev::wave_ext_key_n<true, 64>(lpdev::f64_sort_key(Ml), &whit);
-            const double M = lpdev::f64_from_key(Mk);
+        RS_STAMP_C(4);
+        RS_STAMP_R(14);
+        // ================= consume: everyone's records, one decision (communication wave) ============
+        if (is_comm) {
             int mode, kst = 0, e = -1, r = -1;
-            double ur = 0.0;
-            if (failed) {
-                mode = MODE_FAIL;
-                if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
-            } else if (Mk == kNegInf || !(M > eps)) {
-                mode = MODE_OPTIMAL;                     // the scan's final value is <= M <= eps (:162 / :174)
+            double ur = 0.0, M;
+            unsigned long long Mk;
+            bool failed = false;
+            if (G <= 32) {
+                // one 64-lane sweep reads all the records: lane q the first granule {M_q, column, verdict,
+                // leaving row} of record q, lane 32 + q its second {u_r}; the next sweep is in flight while
+                // this one is tested
+                const int q = lane & 31;
+                const bool live = q < G;
+                const unsigned off = cm.rec + (par * (unsigned)G + (unsigned)(live ? q : 0)) * 32u + (unsigned)(lane >> 5) * 16u;
+                Spin spin;
+                v4i a = ld16(cm.r, off);
+                for (;;) {
+                    v4i a1 = a;
+                    if (!(rd.flags & 8)) a1 = ld16(cm.r, off);   // (experiment, bit 3: one sweep in flight)
+                    const bool ok = !live || r_fresh(a, ep);
+                    if (__all(ok)) break;
+                    if (spin.expired(cm.r, cm.abort)) {
+                        failed = true;
+                        const unsigned long long bad = __ballot(!ok);
+                        if (lane == 0) sh.ctl->pad0 = bad ? (int)(__builtin_ctzll(bad) & 31) : -1;   // first stale record
+                        break;
+                    }
+                    a = (rd.flags & 8) ? ld16(cm.r, off) : a1;
+                }
+                RS_STAMP(0);
+                const unsigned eq = (unsigned)a.x & 0xFFFFu;
+                const bool cand = lane < 32 && live && eq < kCommit;
+                const double Mq = cand ? g_f64(a) : -INFINITY;
+                unsigned long long whit;
+                Mk = lpdev::wave_ext_key_n<true, 32>(lane < 32 ? lpdev::f64_sort_key(Mq) : 0ULL, &whit);
+                M = lpdev::f64_from_key(Mk);
+                if (failed) {
+                    mode = MODE_FAIL;
+                    if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
+                } else if (Mk == kNegInf || !(M > eps)) {
+                    mode = MODE_OPTIMAL;                     // the scan's final value is <= M <= eps (:162 / :174)
+                } else {
+                    const int W = (int)__builtin_ctzll(whit);   // first lane = first workgroup attaining M
+                    // Does M beat everything in front of the winner by more than eps?  (one ballot: fl(v + eps)
+                    // is monotone in v) — and the winner's own verdict on its columns (bit 15)
+                    const unsigned long long near = __ballot(lane < W && !(M > Mq + eps));
+                    kst = W;
+                    e = (int)__builtin_amdgcn_readlane((int)eq, W);
+                    const unsigned misc = (unsigned)__builtin_amdgcn_readlane(a.z, W) & 0xFFFFu;
+                    ur = lpdev::wave_bcast_f64(g_f64(a), W + 32);
+                    r = (int)(misc & 0x7FFu) - 1;
+                    const bool clear = near == 0ULL && (misc & 0x8000u) != 0;
+                    mode = !clear ? MODE_SLOW : (r < 0 ? MODE_UNBOUNDED : MODE_PIVOT);   // :179
+                }
             } else {
-                const int W = (int)__builtin_ctzll(whit);   // first lane = first workgroup attaining M
-                // Does M beat everything in front of the winner's first maximum by more than eps?  The
-                // lanes before the winner's lane (one ballot; fl(v + eps) is monotone, so a lane's
-                // extreme stands for all its records), the records of the winner's own lane in front of
-                // the winner (G > 64 only), and the winner's own verdict on its columns (bit 15)
-                const unsigned long long near =
-                    __ballot((lane < W && !(M > Ml + eps)) || (lane == W && !(M > Mfront + eps)));
-                kst = __builtin_amdgcn_readlane(ql, W);
-                e = (int)__builtin_amdgcn_readlane((int)el, W);
-                const unsigned misc = (unsigned)__builtin_amdgcn_readlane((int)miscl, W);
-                ur = lpdev::wave_bcast_f64(ul, W);
-                r = (int)(misc & 0x7FFu) - 1;
-                const bool clear = near == 0ULL && (misc & 0x8000u) != 0;
-                mode = !clear ? MODE_SLOW : (r < 0 ? MODE_UNBOUNDED : MODE_PIVOT);   // :179
+                // more than 32 workgroups: R consecutive records per lane (lane order = column order)
+                const int R = (G + 63) >> 6;
+                const int q0 = lane * R;
+                double Ml = -INFINITY, Mfront = -INFINITY;
+                unsigned el = kNoColumn, miscl = 0;
+                int ql = -1;
+                double ul = 0.0;
+                Spin spin;
+                for (;;) {
+                    bool ok = true;
+                    Ml = -INFINITY; Mfront = -INFINITY; el = kNoColumn; miscl = 0; ql = -1; ul = 0.0;
+                    for (int t = 0; t < R; ++t) {
+                        const int q = q0 + t;
+                        if (q >= G) break;
+                        const unsigned base = cm.rec + (par * (unsigned)G + (unsigned)q) * 32u;
+                        const v4i a = ld16(cm.r, base), b = ld16(cm.r, base + 16);
+                        ok &= r_fresh(a, ep) && r_fresh(b, ep);
+                        const double Mq = g_f64(a);
+                        const unsigned eq = (unsigned)a.x & 0xFFFFu;
+                        if (eq < kCommit && Mq > Ml) {           // strictly greater: ties keep the earlier column
+                            Mfront = Ml;                         // the extreme of this lane's records in front of it
+                            Ml = Mq;
+                            el = eq;
+                            miscl = (unsigned)a.z & 0xFFFFu;
+                            ul = g_f64(b);
+                            ql = q;
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (spin.expired(cm.r, cm.abort)) {
+                        failed = true;
+                        const unsigned long long bad = __ballot(!ok);
+                        if (lane == 0) sh.ctl->pad0 = bad ? (int)__builtin_ctzll(bad) * R : -1;   // first stale record
+                        break;
+                    }
+                }
+                RS_STAMP(0);
+                unsigned long long whit;
+                Mk = lpdev::wave_ext_key_n<true, 64>(lpdev::f64_sort_key(Ml), &whit);
+                M = lpdev::f64_from_key(Mk);
+                if (failed) {
+                    mode = MODE_FAIL;
+                    if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
+                } else if (Mk == kNegInf || !(M > eps)) {
+                    mode = MODE_OPTIMAL;
+                } else {
+                    const int W = (int)__builtin_ctzll(whit);   // first lane = first workgroup attaining M
+                    // the lanes before the winner's lane (a lane's extreme stands for all its records), the
+                    // records of the winner's own lane in front of the winner, and the winner's own verdict
+                    const unsigned long long near =
+                        __ballot((lane < W && !(M > Ml + eps)) || (lane == W && !(M > Mfront + eps)));
+                    kst = __builtin_amdgcn_readlane(ql, W);
+                    e = (int)__builtin_amdgcn_readlane((int)el, W);
+                    const unsigned misc = (unsigned)__builtin_amdgcn_readlane((int)miscl, W);
+                    ur = lpdev::wave_bcast_f64(ul, W);
+                    r = (int)(misc & 0x7FFu) - 1;
+                    const bool clear = near == 0ULL && (misc & 0x8000u) != 0;
+                    mode = !clear ? MODE_SLOW : (r < 0 ? MODE_UNBOUNDED : MODE_PIVOT);   // :179
+                }
             }
             if (lane == 0) {
                 Ctl* c = sh.ctl;
                 c->mode = mode; c->kst = kst; c->e = e; c->r = r;
                 c->ur = ur; c->dE = M;
             }
-            RS_STAMP(2);
+            RS_STAMP(1);
         }
         __syncthreads();
-        RS_STAMP(3);
+        RS_STAMP_R(6);
         // the whole decision block in one go (three 16-byte LDS reads in flight together)
         Ctl cc = *sh.ctl;
         int mode = cc.mode;
@@ -444,12 +553,12 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         bool from_colS = false;
         if (mode == MODE_SLOW) {
             // ---- exact replay of the scan over all n published reduced costs (near-tie)
-            __syncthreads();   // everyone has read the decision before wave 0 rewrites it
-            if (wave == 0) {
-                // every workgroup reaches this branch for the same pivot: only now are all the reduced
-                // costs published (a near-tie is rare; storing them with every pivot was 512 bytes per
-                // workgroup of traffic in front of the records)
-                if (lane < CPT) st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);
+            __syncthreads();   // everyone has read the decision before the communication wave rewrites it
+            // every workgroup reaches this branch for the same pivot: only now are all the reduced
+            // costs published (a near-tie is rare; storing them with every pivot was 512 bytes per
+            // workgroup of traffic in front of the records)
+            if (wave == 0 && lane < CPT) st16(g_pack(ep, pv), cm.r, cm.dpub + (slot * CPT + (unsigned)lane) * 16u, plain);
+            if (is_comm) {
                 bool failed = false;
                 double best;
                 auto load = [&](int j, bool& ok) {
@@ -484,22 +593,30 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
                 const int e = sh.ctl->e;
                 const int owner = sh.ctl->kst;
                 if (owner == k) {   // second hop: the owner stages the true entering column
-                    const int je = __builtin_amdgcn_readfirstlane(e - col0);
-                    up = RS_SLAB_GET(je);
-                    if (rowok) st16(g_pack(ep, up), cm.r, cm.colS + par * col_stride + (unsigned)tid * 16u, plain);
-                    const double ratio = (rowok && up > eps) ? nan_to(xb / up, INFINITY) : INFINITY;
-                    sh.ratio[tid] = ratio;
-                    sh.u[tid] = up;
-                    lpdev::block_select_stage1_n<false>(ratio, eps, sh.sc);
-                    __syncthreads();
-                    if (wave == 0) {
-                        const int r2 = lpdev::block_select_stage2_n<false, NWMAX, KREPLAY>(sh.ratio, m, eps, sh.sc);
-                        const double ur2 = (r2 >= 0) ? sh.u[r2] : 0.0;
-                        if (lane == 0) st16(r_pack(ep, (unsigned)(r2 + 1), 0u, ur2), cm.r, cm.recS + par * 16u, plain);
+                    if (!is_comm) {
+                        const int je = __builtin_amdgcn_readfirstlane(e - col0);
+                        up = RS_SLAB_GET(je);
+                        if (rowok) st16(g_pack(ep, up), cm.r, cm.colS + par * col_stride + (unsigned)tid * 16u, plain);
+                        const double ratio = (rowok && up > eps) ? nan_to(xb / up, INFINITY) : INFINITY;
+                        sh.ratio[tid] = ratio;
                     }
+                    __syncthreads();
+                    if (is_comm) {   // (rare path: the whole chain on the LDS copy)
+                        double best2;
+                        auto load2 = [&](int j, bool& ok) {
+                            ok = true;
+                            return sh.ratio[j];
+                        };
+                        const int r2 = lpdev::wave_chain_select<false, KREPLAY>(m, eps, best2, load2);
+                        // (the row threads' copy of the column: thread r2 stored it to colS as well)
+                        if (lane == 0) sh.ctl->r = r2;
+                    }
+                    __syncthreads();
+                    const int r2 = sh.ctl->r;
+                    if (tid == (r2 >= 0 ? r2 : 0) && !is_comm) st16(r_pack(ep, (unsigned)(r2 + 1), 0u, r2 >= 0 ? up : 0.0), cm.r, cm.recS + par * 16u, plain);
                 }
-                __syncthreads();   // everyone has read e / owner before wave 0 rewrites the decision
-                if (wave == 0) {
+                __syncthreads();   // everyone has read e / owner before the communication wave rewrites the decision
+                if (is_comm) {
                     Spin spin;
                     bool failed = false;
                     v4i a;
@@ -557,119 +674,120 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         // row's -d_e/u_r; every thread computes them while the pivot row travels through LDS
         const double inv = 1.0 / ur;
         const double lm = -(maximize ? cc.dE : -cc.dE) / ur;
-        RS_STAMP(4);
+        RS_STAMP_R(7);
         __syncthreads();
-        RS_STAMP(5);
-        // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave
-        const double pxb = sh.prow[CPT];
-        if (colok) {
-            dl = (mycol == e) ? 0.0 : fma(lm, sh.prow[lane], dl);
-            if (mycol == e) nbl = false;
-            if (mycol == oldb) nbl = true;
-        }
-        obj = fma(lm, pxb, obj);
-        if (tid == 0) {
-            sh.basis[r] = e;   // :196
-            if (k == 0 && it < d.trace_cap) {
-                d.trace_enter[it] = e;
-                d.trace_leave[it] = r;
-            }
-        }
+        RS_STAMP_R(8);
         ++it;
         const bool last = it >= max_iter;   // :450: this pivot is applied, no further one is chosen
-        if (!last) RS_PRICE();
-        RS_STAMP(6);
-        // ---- the entering column has arrived by now
-        double l;                           // F(i,r), :201 (rows other than r)
-        if (want_col) {
-            Spin spin;
-            while (!g_fresh(gcol, ep_col)) {
-                if (spin.expired(cm.r, cm.abort)) {
-                    sh.ctl->fail = 5;   // code 5: entering column (acted on at the next decision barrier / the commit)
-                    break;
-                }
-                gcol = ld16(cm.r, coff);
+        double xbn = 0.0, upn = 0.0, l = 0.0;
+        if (!is_comm) {
+            // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave
+            const double pxb = sh.prow[CPT];
+            if (colok) {
+                dl = (mycol == e) ? 0.0 : fma(lm, sh.prow[lane], dl);
+                if (mycol == e) nbl = false;
+                if (mycol == oldb) nbl = true;
             }
-            l = (PUBL && !from_colS) ? g_f64(gcol) : -g_f64(gcol) / ur;
-        } else {
-            l = (PUBL && !from_colS) ? lpub : -up / ur;
-        }
-        const double xbn = (tid == r) ? xb * inv : fma(l, pxb, xb);
-        RS_STAMP(7);
-        double upn = 0.0;
-        if (!last) {
-            // the candidate column of the NEXT pivot, updated ahead of the others (same operation,
-            // same operands as the full update below: identical bits)
-            if (jl >= 0) {
+            obj = fma(lm, pxb, obj);
+            if (tid == 0) {
+                sh.basis[r] = e;   // :196
+                if (k == 0 && it - 1 < d.trace_cap) {
+                    d.trace_enter[it - 1] = e;
+                    d.trace_leave[it - 1] = r;
+                }
+            }
+            if (!last) RS_PRICE();
+            RS_STAMP(9);
+            // ---- the entering column has arrived by now: F(i,r), :201 (rows other than r)
+            if (want_col) {
+                Spin spin;
+                while (!g_fresh(gcol, ep_col)) {
+                    if (spin.expired(cm.r, cm.abort)) {
+                        sh.ctl->fail = 5;   // code 5: entering column (acted on at the next decision barrier / the commit)
+                        break;
+                    }
+                    gcol = ld16(cm.r, coff);
+                }
+                l = (PUBL && !from_colS) ? g_f64(gcol) : -g_f64(gcol) / ur;
+            } else {
+                l = (PUBL && !from_colS) ? lpub : -up / ur;
+            }
+            xbn = (tid == r) ? xb * inv : fma(l, pxb, xb);
+            RS_STAMP(10);
+            if (!last && jl >= 0) {
+                // the candidate column of the NEXT pivot, updated ahead of the others (same operation,
+                // same operands as the full update below: identical bits)
                 const double t = RS_SLAB_GET(jl);
                 upn = (tid == r) ? t * inv : fma(l, sh.prow[jl], t);
             }
-            RS_PUBLISH(upn, xbn);
         }
-        RS_STAMP(10);
-        // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204);
-        // the record published above is travelling meanwhile
-        if (rowok) {
-            if (tid == r) {
+        if (!last) RS_CANDIDATE(upn, xbn);
+        if (!is_comm) {
+            // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204);
+            // the record published above is travelling meanwhile
+            if (rowok) {
+                if (tid == r) {
 #pragma unroll
-                for (int j = 0; j < HALF; ++j) {
-                    Ta[j] = Ta[j] * inv;
-                    Tb[j] = Tb[j] * inv;
+                    for (int j = 0; j < HALF; ++j) {
+                        Ta[j] = Ta[j] * inv;
+                        Tb[j] = Tb[j] * inv;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HALF; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < HALF; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
             }
         }
         if (!last) RS_PUBLISH_COLUMN(upn);
-        if (rowok) {
-            if (tid != r) {
+        if (!is_comm) {
+            if (rowok) {
+                if (tid != r) {
 #pragma unroll
-                for (int j = 0; j < HALF; ++j) Tb[j] = fma(l, sh.prow[HALF + j], Tb[j]);
-            }
-            if (kst == k) {   // column e becomes the unit vector
-                const double unit = (tid == r) ? 1.0 : 0.0;
-                switch (e - col0) {
+                    for (int j = 0; j < HALF; ++j) Tb[j] = fma(l, sh.prow[HALF + j], Tb[j]);
+                }
+                if (kst == k) {   // column e becomes the unit vector
+                    const double unit = (tid == r) ? 1.0 : 0.0;
+                    switch (e - col0) {
 #define RS_CASE(J)                                        \
     case J: if (J < HALF) Ta[J & (HALF - 1)] = unit; break;          \
     case HALF + J: if (J < HALF) Tb[J & (HALF - 1)] = unit; break;
-                    RS_CASE(0) RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
-#undef RS_CASE
-                    default: break;
-                }
-                if (HALF == 16) {
-                    switch (e - col0) {
-#define RS_CASE(J)                                        \
-    case J: Ta[J & (HALF - 1)] = unit; break;             \
-    case 16 + J: Tb[J & (HALF - 1)] = unit; break;
-                        RS_CASE(8) RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15)
+                        RS_CASE(0) RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
 #undef RS_CASE
                         default: break;
                     }
+                    if (HALF == 16) {
+                        switch (e - col0) {
+#define RS_CASE(J)                                        \
+    case J: Ta[J & (HALF - 1)] = unit; break;             \
+    case 16 + J: Tb[J & (HALF - 1)] = unit; break;
+                            RS_CASE(8) RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15)
+#undef RS_CASE
+                            default: break;
+                        }
+                    }
                 }
             }
+            xb = xbn;
+            up = upn;
+            RS_STAMP(13);
         }
-        if (!last) RS_PREFETCH();   // first poll of the records: by now they are mostly out
-        xb = xbn;
-        up = upn;
-        RS_STAMP(11);
         if (last) status = LP_ITER_LIMIT;
     }
 #undef RS_PRICE
-#undef RS_PUBLISH
+#undef RS_CANDIDATE
 #undef RS_PUBLISH_COLUMN
-#undef RS_PREFETCH
 
     // ================= commit: the tableau goes home only if EVERY workgroup got here =================
     // One more hop in the ordinary record stream (epoch ep + 1): "I have finished".  A workgroup that
     // failed anywhere — also one whose entering column timed out on the very last pivot — raises the
     // abort word instead, which every spin of the others observes; nobody writes anything back then.
+    __syncthreads();   // (a row thread's late fail = 5 is visible to everyone below)
     if (status != kResidentFailed && sh.ctl->fail) status = kResidentFailed;
     if (status != kResidentFailed) {
         ++ep;
         par = ep & 1u;
         slot = par * (unsigned)G + (unsigned)k;
-        if (wave == 0) {
+        if (is_comm) {
             if (lane < 2) st16(r_pack(ep, kCommit, 0u, 0.0), cm.r, cm.rec + slot * 32u + (unsigned)lane * 16u, plain);
             Spin spin;
             bool failed = false;
@@ -691,8 +809,11 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         __syncthreads();
         if (sh.ctl->fail) status = kResidentFailed;
     }
-    RS_STAMP(12);
+    RS_STAMP_C(5);
+    RS_STAMP_R(15);
 #undef RS_STAMP
+#undef RS_STAMP_C
+#undef RS_STAMP_R
     if (status == kResidentFailed) {   // nothing is written back: the host reruns on another path
         if (tid == 0) {
             // first failing workgroup records where it stopped: {code, workgroup, epoch} (diagnostic)
@@ -704,8 +825,10 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         }
         return;
     }
-    if (STAMPS && rd.stamps && tid == 0)
-        for (int q = 0; q < 16; ++q) rd.stamps[(size_t)k * 16 + q] = acc[q];
+    if (STAMPS && rd.stamps && (tid == 0 || (is_comm && lane == 0))) {
+        const int q0 = is_comm ? 0 : 6, q1 = is_comm ? 6 : 16;
+        for (int q = q0; q < q1; ++q) rd.stamps[(size_t)k * 16 + q] = acc[q];
+    }
     // ---- write the tableau back (row-major (m+1) x ld, what every other entry point reads)
     if (rowok) {
         double* Trow = d.T + (size_t)tid * ld;
@@ -721,7 +844,7 @@ __global__ __launch_bounds__(NT) void k_simplex_resident(SimplexDev d, ResidentD
         d.nonbasic[mycol] = nbl ? 1 : 0;
     }
     if (k == 0) {
-        for (int i = tid; i < m; i += mpad) d.basis[i] = sh.basis[i];
+        for (int i = tid; i < m; i += mpad + 64) d.basis[i] = sh.basis[i];
         if (tid == 0) {
             d.T[(size_t)m * ld + n] = obj;
             st->iters = it;
@@ -750,7 +873,7 @@ void launch_resident(const SimplexDev& d, const ResidentDev& rd, size_t shm, hip
         *attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_resident<CPT, NT, ST, PL>),             \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                           \
         if (*attr_err == hipSuccess)                                                                                     \
-            hipLaunchKernelGGL((k_simplex_resident<CPT, NT, ST, PL>), rd.G * rd.stride, rd.mpad, shm, s, d, rd);         \
+            hipLaunchKernelGGL((k_simplex_resident<CPT, NT, ST, PL>), rd.G * rd.stride, rd.mpad + 64, shm, s, d, rd);         \
     } while (0)
     if (stamped)
         RS_GO(true, true);
@@ -765,8 +888,8 @@ void launch_resident(const SimplexDev& d, const ResidentDev& rd, size_t shm, hip
 
 // Shape check + buffer plan.  Returns 1 and fills *out if the chip-resident path can run (m, n).
 int lp_resident_plan(int m, int n, ResidentDev* out) {
-    if (m < 1 || m > 1024 || n < m) return 0;   // one row per thread
-    const int cpt = m <= 512 ? 32 : 16;         // 512 threads x 32 columns (193 VGPRs) or 1024 x 16 (<= 128)
+    if (m < 1 || m > 960 || n < m) return 0;    // one row per thread, plus the communication wave: <= 1024 threads
+    const int cpt = m <= 512 ? 32 : 16;         // 512 row threads x 32 columns (<= 168 VGPRs at 9 waves) or 960 x 16 (<= 128)
     const int G = (n + cpt - 1) / cpt;
     if (G > RS_MAX_G) return 0;
     if (n > 0xFFF0) return 0;                   // the record carries the column in 16 bits
@@ -808,6 +931,8 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     if (getenv("LP_RESIDENT_FORCE_SC1")) rdv.flags |= 1;     // diagnostics: write-through stores on one XCD too
     if (getenv("LP_RESIDENT_SPREAD")) rdv.stride = 1;        // diagnostics: participants on all XCDs
     if (getenv("LP_RESIDENT_INJECT_FAILURE")) rdv.flags |= 2;   // tests: the census reports a failure
+    if (getenv("LP_RESIDENT_DRAIN")) rdv.flags |= 4;            // experiments
+    if (getenv("LP_RESIDENT_ONESWEEP")) rdv.flags |= 8;
     const bool pubu = getenv("LP_RESIDENT_PUBU") != nullptr; // A/B: publish u_i (consumers divide)
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_resident_state_init, 1, 1, 0, s, d, eps, max_iter);
@@ -821,7 +946,7 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     if (rd.cpt == 32)
         launch_resident<32, 512>(d, rdv, shm, s, stamped, pubu, &attr_err);
     else
-        launch_resident<16, 1024>(d, rdv, shm, s, stamped, pubu, &attr_err);
+        launch_resident<16, 960>(d, rdv, shm, s, stamped, pubu, &attr_err);
     LP_HIP(ctx, attr_err);
     LP_HIP(ctx, hipEventRecord(p->res_ev1, s));
     LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
@@ -839,6 +964,28 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
         snprintf(msg, sizeof(msg), "chip-resident simplex: hand-off timed out (code*1000+workgroup %d, epoch*1000+record %d), "
                  "re-running on the launch-based path", p->h_state->enter, p->h_state->leave);
         ctx->last_error = msg;
+        if (getenv("LP_RESIDENT_DEBUG")) {   // the record area as the failure left it
+            std::vector<int> rec((size_t)2 * rd.G * 8);
+            if (hipMemcpy(rec.data(), rd.comm + rd.rec_off, rec.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int par = 0; par < 2; ++par)
+                    for (int q = 0; q < rd.G; ++q) {
+                        const int* w = &rec[((size_t)par * rd.G + q) * 8];
+                        fprintf(stderr, "[resident debug] parity %d record %3d: %08x %08x %08x %08x | %08x %08x %08x %08x\n", par, q,
+                                w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+                    }
+            }
+        }
+        if (stamped && getenv("LP_RESIDENT_DEBUG")) {   // diagnostic instantiation: where every wave of every workgroup stopped
+            std::vector<unsigned long long> prog(16 * 256);
+            if (hipMemcpy(prog.data(), rd.stamps + 16 * 256, prog.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int q = 0; q < rd.G; ++q) {
+                    fprintf(stderr, "[resident debug] workgroup %3d, last stamp of waves 0..%d (epoch*100 + slot):", q, rd.mpad / 64);
+                    for (int w = 0; w <= rd.mpad / 64; ++w) fprintf(stderr, " %llu", prog[(size_t)q * 16 + w]);
+                    fprintf(stderr, "  census %llu", prog[(size_t)q * 16 + 15]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
         if (getenv("LP_RESIDENT_STRICT")) return LP_BAD_ARG;   // tests: a fallback must not hide a protocol bug
         int rc;
         if (p->look.J >= 2) {
