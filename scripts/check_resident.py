@@ -1,5 +1,5 @@
 """Quick GPU check of the chip-resident simplex: parity against the oracle on a few shapes,
-timing at 512 x 1024 (and of the forms kept for A/B: LP_RESIDENT_PUBU, the round-2 kernel) and the
+timing at 512 x 1024 (and of the forms kept for A/B: LP_RESIDENT_PUBL, the round-2 kernel) and the
 per-phase cycle stamps of workgroup 0."""
 import ctypes as C
 import os
@@ -59,11 +59,11 @@ A, b, c, basis = lpcases.random_lp(0, 512, 1024)
 p = ctx.simplex_problem(A, b, c, basis, True, 512)
 for rnd in range(2):
     best, st = best_of(p, capi.SIMPLEX_RESIDENT)
-    print("resident (eta column published): 512x1024 %d pivots best solve_ms=%.4f -> %.3f us/pivot" % (st.pivots, best, 1e3 * best / st.pivots), flush=True)
-    os.environ["LP_RESIDENT_PUBU"] = "1"
+    print("resident (column u published, default): 512x1024 %d pivots best solve_ms=%.4f -> %.3f us/pivot" % (st.pivots, best, 1e3 * best / st.pivots), flush=True)
+    os.environ["LP_RESIDENT_PUBL"] = "1"
     best, st = best_of(p, capi.SIMPLEX_RESIDENT)
-    del os.environ["LP_RESIDENT_PUBU"]
-    print("resident (column u published)  : best solve_ms=%.4f -> %.3f us/pivot" % (best, 1e3 * best / st.pivots), flush=True)
+    del os.environ["LP_RESIDENT_PUBL"]
+    print("resident (eta column published)        : best solve_ms=%.4f -> %.3f us/pivot" % (best, 1e3 * best / st.pivots), flush=True)
     os.environ["LP_RESIDENT_V1"] = "1"
     p1 = ctx.simplex_problem(A, b, c, basis, True, 512)
     del os.environ["LP_RESIDENT_V1"]

@@ -10,7 +10,7 @@ for seed, m, n in [(0, 512, 1024)]:
     A, b, c, basis = lpcases.random_lp(seed, m, n)
     probs.append((m, n, ctx.simplex_problem(A, b, c, basis, True, n - m)))
 for mode in ([], ["LP_RESIDENT_DRAIN"], ["LP_RESIDENT_ONESWEEP"], ["LP_RESIDENT_DRAIN", "LP_RESIDENT_ONESWEEP"],
-             ["LP_RESIDENT_PUBU"], ["LP_RESIDENT_SPREAD"], ["LP_RESIDENT_SPREAD", "LP_RESIDENT_DRAIN"], ["LP_RESIDENT_FORCE_SC1"],
+             ["LP_RESIDENT_PUBL"], ["LP_RESIDENT_SPREAD"], ["LP_RESIDENT_SPREAD", "LP_RESIDENT_DRAIN"], ["LP_RESIDENT_FORCE_SC1"],
              ["LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_DRAIN"]):
     for v in mode:
         os.environ[v] = "1"

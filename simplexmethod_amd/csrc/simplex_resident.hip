@@ -44,6 +44,11 @@
 #include "lp_internal.hpp"
 #include "simplex_problem.hpp"
 
+#ifndef RS_MARK_A
+#define RS_MARK_A (-1)
+#define RS_MARK_B (-1)
+#endif
+
 namespace {
 
 constexpr int kRunning = -100;
@@ -128,11 +133,41 @@ struct Shared {
     Ctl* ctl;
     v4i* pub;        // {epoch, u_r.lo, epoch, u_r.hi} of my candidate, from the communication wave
     int* basis;      // mpad      : N by position (every workgroup keeps its own copy)
+    SimplexDev* stash;   // the kernel's arguments for the epilogue: re-read from here, the pivot loop is ~100 SGPRs
+                         // short and every uniform value kept live across it is reloaded by v_readlane chains
 };
 
+// reload of a structure the compiler shall not connect with its original (dword by dword through a volatile view)
+template <typename T>
+__device__ __forceinline__ T lds_reload(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized");
+    T out;
+    const volatile int* src = reinterpret_cast<const volatile int*>(p);
+    int* dst = reinterpret_cast<int*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
+    return out;
+}
+
 __host__ __device__ inline size_t resident_lds_bytes(int mpad, int cpt) {
-    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + 512 /* SelScratch */ + sizeof(Ctl) + 16 +
-           sizeof(int) * (size_t)mpad;
+    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + 2048 /* SelScratch */ + sizeof(Ctl) + 16 +
+           sizeof(int) * (size_t)mpad + 256 /* stash */;
+}
+
+// Read of the decision block's head {mode, kst, e, r} and of the failure flag (the pivot element and the
+// scan value are read where the rare paths need them)
+__device__ __forceinline__ Ctl ctl_read_head(const Ctl* p) {
+    const v4i a = *reinterpret_cast<const v4i*>(p);
+    const int f = p->fail;
+    Ctl o;
+    o.mode = __builtin_amdgcn_readfirstlane(a.x);
+    o.kst = __builtin_amdgcn_readfirstlane(a.y);
+    o.e = __builtin_amdgcn_readfirstlane(a.z);
+    o.r = __builtin_amdgcn_readfirstlane(a.w);
+    o.ur = 0.0; o.dE = 0.0;
+    o.fail = __builtin_amdgcn_readfirstlane(f);
+    o.plain = 0; o.pad0 = 0; o.pad1 = 0;
+    return o;
 }
 
 struct Comm {   // buffer descriptor and byte offsets of the hand-off areas (all inside rd.comm)
@@ -145,19 +180,23 @@ struct Comm {   // buffer descriptor and byte offsets of the hand-off areas (all
 __device__ __forceinline__ double nan_to(double v, double sentinel) { return (v == v) ? v : sentinel; }
 
 struct SelScratch {   // LDS: ratio-test slice summaries (one per row wave) and the pricing summary of the candidate
-    unsigned long long M[16];   // sortable key of the slice's smallest ratio
-    double U[16];               // the candidate column's entry at the slice's first minimum
-    int ok[16];                 // "the slice's minimum beats everything of the slice in front of it by more than eps"
-    int J[16];                  // row of the slice's first minimum (INT_MAX: nothing eligible)
+    // (64 entries each: entries past the row waves keep the identity written once at kernel start, so the
+    // communication wave loads them with every lane and no lane mask)
+    unsigned long long M[64];   // sortable key of the slice's smallest ratio
+    double U[64];               // the candidate column's entry at the slice's first minimum
+    int ok[64];                 // "the slice's minimum beats everything of the slice in front of it by more than eps"
+    int J[64];                  // row of the slice's first minimum (INT_MAX: nothing eligible)
     unsigned long long pM;      // sortable key of M_k, the extreme reduced cost of my columns
     int pJ, pOk;                // its first column (local index, -1: none eligible); verdict on my columns in front of it
 };
-static_assert(sizeof(SelScratch) <= 512 && sizeof(SelScratch) % 16 == 0, "resident_lds_bytes reserves 512 bytes, 16-byte aligned");
+static_assert(sizeof(SelScratch) <= 2048 && sizeof(SelScratch) % 16 == 0, "resident_lds_bytes reserves 2048 bytes, 16-byte aligned");
 
 // CPT columns per workgroup; NT = upper bound of the row threads (the launch uses mpad = m rounded up to
 // 64 row threads PLUS ONE COMMUNICATION WAVE: blockDim = mpad + 64).
-// PUBL: the published column is the eta column -u_i/u_r (the consumers' division comes off the
-//       critical path); !PUBL (A/B, LP_RESIDENT_PUBU=1): u_i itself, stored before the ratio test.
+// !PUBL (the default): the published column is u_i itself, stored before the ratio test, and the consumers
+//       divide by the record's u_r; PUBL (A/B, LP_RESIDENT_PUBL=1): the eta column -u_i/u_r, published by
+//       the rows behind their rank-1 update once the communication wave has handed them u_r (the consumers'
+//       division comes off the critical path, but the whole pivot measured 0.15 us longer).
 template <int CPT, int NT, bool STAMPS, bool PUBL>
 __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, ResidentDev rd) {
     static_assert(CPT == 32 || CPT == 16, "the slab is two vectors of 16 or 8 doubles");
@@ -185,8 +224,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     const bool maximize = d.maximize != 0;
     const double eps = st->eps;
     const int max_iter = st->max_iter;
-    const unsigned long long kNegInf = lpdev::f64_sort_key(-INFINITY);
-    const unsigned long long kPosInf = lpdev::f64_sort_key(INFINITY);
+    constexpr unsigned long long kNegInf = 0x000FFFFFFFFFFFFFull;   // f64_sort_key(-inf)
+    constexpr unsigned long long kPosInf = 0xFFF0000000000000ull;   // f64_sort_key(+inf)
 
     Shared sh;
     sh.prow = smem;
@@ -196,6 +235,9 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     sh.ctl = reinterpret_cast<Ctl*>(sh.sel + 1);
     sh.pub = reinterpret_cast<v4i*>(sh.ctl + 1);
     sh.basis = reinterpret_cast<int*>(sh.pub + 1);
+    sh.stash = reinterpret_cast<SimplexDev*>(sh.basis + mpad);
+    static_assert(sizeof(SimplexDev) <= 256, "resident_lds_bytes reserves 256 bytes for the stash");
+    if (tid == 0) *sh.stash = d;
 
     Comm cm;
     cm.r = __builtin_amdgcn_make_buffer_rsrc(rd.comm, 0, rd.comm_bytes, 0x00020000);
@@ -233,6 +275,10 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 15u;
+        sh.sel->M[lane] = kPosInf;   // identity of the ratio test's slice table
+        sh.sel->U[lane] = 0.0;
+        sh.sel->ok[lane] = 0;
+        sh.sel->J[lane] = INT_MAX;
         if (lane == 0) {
             v4i g = {1, (int)xcc, 1, 0};
             st16(g, cm.r, cm.census + (unsigned)k * 16u, false);
@@ -285,6 +331,20 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     } while (0)
 #define RS_STAMP_C(s) do { if (is_comm) RS_STAMP(s); } while (0)
 #define RS_STAMP_R(s) do { if (!is_comm) RS_STAMP(s); } while (0)
+    // Interval timer of diagnostic builds (-DRS_MARK_A=a -DRS_MARK_B=b, scripts/resident_marks.py): cycles from
+    // mark a to the next mark b of the communication wave (marks 0-9) or of row wave 0 (marks 10-29), summed
+    // over the solve: two clock reads per pivot instead of a stamp per phase, so the rest runs undisturbed.
+    unsigned long long mk_t = 0, mk_acc = 0;
+#define RS_MARK(id)                                                                    \
+    do {                                                                               \
+        if ((id) == RS_MARK_A) mk_t = __builtin_readcyclecounter();                    \
+        if ((id) == RS_MARK_B && mk_t) {                                               \
+            mk_acc += __builtin_readcyclecounter() - mk_t;                             \
+            mk_t = 0;                                                                  \
+        }                                                                              \
+    } while (0)
+#define RS_MARK_C(id) do { if (RS_MARK_A >= 0 && is_comm) RS_MARK(id); } while (0)
+#define RS_MARK_R(id) do { if (RS_MARK_A >= 0 && wave == 0) RS_MARK(id); } while (0)
 
     unsigned ep = 0, par = 0, slot = 0;
     double pv = 0.0;
@@ -301,6 +361,27 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         mkey = lpdev::wave_ext_key_n<true, CPT>(pkey, &hit);                       \
         if (mkey == kNegInf) hit = 0;                                              \
         jl = hit ? (int)__builtin_ctzll(hit) : -1;                                 \
+    } while (0)
+
+    // my part of the pivot row (before scaling) and xB_r, broadcast through LDS by the thread that owns row RR
+#define RS_STAGE_PROW(RR)                                     \
+    do {                                                      \
+        if (tid == (RR)) {                                    \
+            _Pragma("unroll") for (int j = 0; j < HALF; ++j) { \
+                sh.prow[j] = Ta[j];                           \
+                sh.prow[HALF + j] = Tb[j];                    \
+            }                                                 \
+            sh.prow[CPT] = xb;                                \
+        }                                                     \
+    } while (0)
+    // the two wave-uniform quotients of the update, by the communication wave: F(r,r) = 1/u_r (:204) and the
+    // reduced-cost row's -d_e/u_r (two divisions off every row wave's path); they travel with the pivot row
+#define RS_QUOTIENTS(UR, DE)                                                    \
+    do {                                                                        \
+        if (lane == 0) {                                                        \
+            sh.prow[CPT + 1] = 1.0 / (UR);                                      \
+            sh.prow[CPT + 2] = -(maximize ? (DE) : -(DE)) / (UR);               \
+        }                                                                       \
     } while (0)
 
     // Candidate (column values UP for the rows, xB values XBV).  Row waves: first half of the ratio test
@@ -346,8 +427,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }                                                                                            \
         RS_STAMP_R(11);                                                                              \
         RS_STAMP_C(2);                                                                               \
+        RS_MARK_R(16);                                                                               \
         __syncthreads();                                                                             \
         RS_STAMP_R(12);                                                                              \
+        RS_MARK_R(17);                                                                               \
+        RS_MARK_C(5);                                                                                \
         if (is_comm) {                                                                               \
             const int pJ_ = sh.sel->pJ;                                                              \
             const int pOk_ = sh.sel->pOk;                                                            \
@@ -355,13 +439,14 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             int rk = -1;                                                                             \
             double urk = 0.0;                                                                        \
             if (pJ_ >= 0) {                                                                          \
-                const bool has_ = lane < nrw;                                                        \
-                const unsigned long long Ml_ = has_ ? sh.sel->M[lane & 15] : kPosInf;                \
-                const int okl_ = has_ ? sh.sel->ok[lane & 15] : 0;                                   \
-                const int Jl_ = has_ ? sh.sel->J[lane & 15] : INT_MAX;                               \
-                const double Ul_ = has_ ? sh.sel->U[lane & 15] : 0.0;                                \
+                const unsigned long long Ml_ = sh.sel->M[lane];                                      \
+                const int okl_ = sh.sel->ok[lane];                                                   \
+                const int Jl_ = sh.sel->J[lane];                                                     \
+                const double Ul_ = sh.sel->U[lane];                                                  \
+                if (RS_MARK_A >= 30) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RS_MARK(30); } \
                 unsigned long long h2_;                                                              \
                 const unsigned long long M2_ = lpdev::wave_ext_key_n<false, NWMAX>(Ml_, &h2_);       \
+                RS_MARK(31);                                                                         \
                 if (M2_ != kPosInf) {                                                                \
                     const int W_ = (int)__builtin_ctzll(h2_);   /* first slice attaining the minimum (row order) */ \
                     const int jM_ = __builtin_amdgcn_readlane(Jl_, W_);                              \
@@ -383,15 +468,16 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     }                                                                                \
                 }                                                                                    \
             }                                                                                        \
+            RS_MARK(32);                                                                             \
             if (lane < 2) {                                                                          \
                 const v4i g = lane == 0 ? r_pack(ep, pJ_ >= 0 ? (unsigned)(col0 + pJ_) : kNoColumn,  \
                                                  (pOk_ ? 0x8000u : 0u) | (unsigned)(rk + 1), lpdev::f64_from_key(pM_)) \
                                         : r_pack(ep, 0u, 0u, urk);                                   \
                 st16(g, cm.r, cm.rec + slot * 32u + (unsigned)lane * 16u, plain);                    \
             }                                                                                        \
-            if (rd.flags & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* experiment: drain the record store */ \
             if (PUBL && lane == 0) *sh.pub = g_pack(ep, urk);   /* read behind RS_PUBLISH_COLUMN's barrier */ \
             RS_STAMP(3);                                                                             \
+            RS_MARK_C(6);                                                                            \
         }                                                                                            \
     } while (0)
 
@@ -402,15 +488,37 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     // and older waves spinning there starved it — its record came out 200 ms late or never.
 #define RS_PUBLISH_COLUMN(UP)                                                                        \
     do {                                                                                             \
-        if (PUBL) {                                                                                  \
-            __syncthreads();                                                                         \
-            if (!is_comm && jl >= 0) {                                                               \
-                lpub = -(UP) / g_f64(*sh.pub);                                                       \
-                if (rowok) st16(g_pack(ep, lpub), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
+        if (PUBL && !is_comm && jl >= 0) {                                                           \
+            /* u_r has been in LDS for hundreds of cycles when the rows get here (their update is longer than  \
+               the communication wave's half of the ratio test); should it not be, they SLEEP between looks: \
+               older waves spinning on an LDS word starved the communication wave, the youngest of its SIMD */ \
+            v4i pg_ = lds_granules(sh.pub);                                                          \
+            for (unsigned spins_ = 0; !g_fresh(pg_, ep) && spins_ < (1u << 20); ++spins_) {          \
+                __builtin_amdgcn_s_sleep(8);                                                         \
+                pg_ = lds_granules(sh.pub);                                                          \
             }                                                                                        \
+            if (!g_fresh(pg_, ep)) sh.ctl->fail = 6;   /* code 6: u_r never came */                  \
+            lpub = -(UP) / g_f64(pg_);                                                               \
+            if (rowok) st16(g_pack(ep, lpub), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
         }                                                                                            \
     } while (0)
 
+    int bk_e = -1, bk_r = -1;
+    // bookkeeping of the communication wave, off everybody's path
+#define RS_BOOKKEEP()                                                                                   \
+    do {                                                                                                \
+        if (is_comm && lane == 0 && bk_r >= 0) {                                                        \
+            sh.basis[bk_r] = bk_e;                                                                      \
+            if (k == 0) {   /* (workgroup 0 only: the trace pointers come from the stash, not from SGPRs held all along) */ \
+                const SimplexDev dt = lds_reload(sh.stash);                                             \
+                if (it - 1 < dt.trace_cap) {                                                            \
+                    dt.trace_enter[it - 1] = bk_e;                                                      \
+                    dt.trace_leave[it - 1] = bk_r;                                                      \
+                }                                                                                       \
+            }                                                                                           \
+            bk_r = -1;                                                                                  \
+        }                                                                                               \
+    } while (0)
     double up = 0.0;
     if (status == kRunning) {   // prologue: candidate of the initial tableau
         if (!is_comm) {
@@ -423,6 +531,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     while (status == kRunning) {
         RS_STAMP_C(4);
         RS_STAMP_R(14);
+        RS_MARK_C(0);
+        RS_MARK_R(20);
         // ================= consume: everyone's records, one decision (communication wave) ============
         if (is_comm) {
             int mode, kst = 0, e = -1, r = -1;
@@ -439,8 +549,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 Spin spin;
                 v4i a = ld16(cm.r, off);
                 for (;;) {
-                    v4i a1 = a;
-                    if (!(rd.flags & 8)) a1 = ld16(cm.r, off);   // (experiment, bit 3: one sweep in flight)
+                    const v4i a1 = ld16(cm.r, off);
                     const bool ok = !live || r_fresh(a, ep);
                     if (__all(ok)) break;
                     if (spin.expired(cm.r, cm.abort)) {
@@ -449,15 +558,17 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                         if (lane == 0) sh.ctl->pad0 = bad ? (int)(__builtin_ctzll(bad) & 31) : -1;   // first stale record
                         break;
                     }
-                    a = (rd.flags & 8) ? ld16(cm.r, off) : a1;
+                    a = a1;
                 }
                 RS_STAMP(0);
+                RS_MARK_C(1);
                 const unsigned eq = (unsigned)a.x & 0xFFFFu;
                 const bool cand = lane < 32 && live && eq < kCommit;
                 const double Mq = cand ? g_f64(a) : -INFINITY;
                 unsigned long long whit;
                 Mk = lpdev::wave_ext_key_n<true, 32>(lane < 32 ? lpdev::f64_sort_key(Mq) : 0ULL, &whit);
                 M = lpdev::f64_from_key(Mk);
+                RS_MARK(34);
                 if (failed) {
                     mode = MODE_FAIL;
                     if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
@@ -514,9 +625,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     }
                 }
                 RS_STAMP(0);
+                RS_MARK_C(1);
                 unsigned long long whit;
                 Mk = lpdev::wave_ext_key_n<true, 64>(lpdev::f64_sort_key(Ml), &whit);
                 M = lpdev::f64_from_key(Mk);
+
                 if (failed) {
                     mode = MODE_FAIL;
                     if (lane == 0) sh.ctl->fail = 2;   // code 2: record poll
@@ -539,15 +652,20 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             }
             if (lane == 0) {
                 Ctl* c = sh.ctl;
-                c->mode = mode; c->kst = kst; c->e = e; c->r = r;
+                const v4i head = {mode, kst, e, r};
+                *reinterpret_cast<v4i*>(c) = head;
                 c->ur = ur; c->dE = M;
             }
             RS_STAMP(1);
+            RS_MARK_C(2);
         }
-        __syncthreads();
+        __syncthreads();   // the decision barrier
         RS_STAMP_R(6);
-        // the whole decision block in one go (three 16-byte LDS reads in flight together)
-        Ctl cc = *sh.ctl;
+        RS_MARK_C(3);
+        RS_MARK_R(10);
+        // the whole decision block in one go (three 16-byte LDS reads in flight together), by ONE lane: a
+        // broadcast read costs the LDS all 64 lanes' bandwidth, and every wave asks at this moment
+        Ctl cc = ctl_read_head(sh.ctl);
         int mode = cc.mode;
         if (cc.fail) mode = MODE_FAIL;
         bool from_colS = false;
@@ -638,7 +756,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     }
                 }
                 __syncthreads();
-                cc = *sh.ctl;
+                cc = ctl_read_head(sh.ctl);
                 mode = cc.mode;
                 from_colS = true;
             }
@@ -647,10 +765,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             status = mode == MODE_OPTIMAL ? LP_OPTIMAL : mode == MODE_UNBOUNDED ? LP_UNBOUNDED : kResidentFailed;
             break;
         }
-        const int kst = __builtin_amdgcn_readfirstlane(cc.kst);
-        const int e = __builtin_amdgcn_readfirstlane(cc.e);
-        const int r = __builtin_amdgcn_readfirstlane(cc.r);
-        const double ur = cc.ur;
+        const int kst = cc.kst, e = cc.e, r = cc.r;
+        RS_MARK_R(11);
         // ---- entering column: the winner's published eta column (mine is still in a register; after
         // the slow path it is the owner's second-hop column of u_i)
         const bool want_col = kst != k && rowok;
@@ -660,44 +776,45 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         v4i gcol = {0, 0, 0, 0};
         const unsigned ep_col = ep;
         if (want_col) gcol = ld16(cm.r, coff);   // awaited after the next pricing
-        // ---- my part of the pivot row (before scaling), broadcast through LDS
-        if (tid == r) {
-#pragma unroll
-            for (int j = 0; j < HALF; ++j) {
-                sh.prow[j] = Ta[j];
-                sh.prow[HALF + j] = Tb[j];
-            }
-            sh.prow[CPT] = xb;
-        }
-        const int oldb = sh.basis[r];    // (rewritten behind the next barrier)
-        // the two wave-uniform quotients of the update: F(r,r) = 1/u_r (:204) and the reduced-cost
-        // row's -d_e/u_r; every thread computes them while the pivot row travels through LDS
-        const double inv = 1.0 / ur;
-        const double lm = -(maximize ? cc.dE : -cc.dE) / ur;
+        // ---- my part of the pivot row (before scaling) through LDS, by its owner; the communication wave
+        // (idle until the ratio barrier) adds the two quotients of the update meanwhile
+        if (is_comm)
+            RS_QUOTIENTS(sh.ctl->ur, sh.ctl->dE);
+        else
+            RS_STAGE_PROW(r);
+        const int oldb = sh.basis[r];    // (rewritten by the communication wave behind a later barrier)
         RS_STAMP_R(7);
-        __syncthreads();
+        RS_MARK_R(12);
+        __syncthreads();   // the pivot-row barrier
         RS_STAMP_R(8);
+        RS_MARK_C(4);
+        RS_MARK_R(13);
         ++it;
         const bool last = it >= max_iter;   // :450: this pivot is applied, no further one is chosen
-        double xbn = 0.0, upn = 0.0, l = 0.0;
-        if (!is_comm) {
-            // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave
-            const double pxb = sh.prow[CPT];
+        double xbn = 0.0, upn = 0.0, l = 0.0, inv = 0.0;
+        if (is_comm) {
+            // N(leave_pos) = enter (:196) and the trace, in this wave's idle window (it has nothing to do until the
+            // ratio barrier) and behind the pivot-row barrier: every row wave has read the old basis entry
+            bk_e = e;
+            bk_r = r;
+            RS_BOOKKEEP();
+        } else {
+            // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave.  ONE LDS read
+            // per wave: lane j takes pivot-row entry j (lane CPT: xB_r); the two wave-uniform entries needed
+            // below (xB_r and the candidate's) come out of these registers by v_readlane
+            const double pl = sh.prow[lane <= CPT + 2 ? lane : 0];
+            const double pxb = lpdev::wave_bcast_f64(pl, CPT);
+            inv = lpdev::wave_bcast_f64(pl, CPT + 1);
+            const double lm = lpdev::wave_bcast_f64(pl, CPT + 2);
             if (colok) {
-                dl = (mycol == e) ? 0.0 : fma(lm, sh.prow[lane], dl);
+                dl = (mycol == e) ? 0.0 : fma(lm, pl, dl);
                 if (mycol == e) nbl = false;
                 if (mycol == oldb) nbl = true;
             }
             obj = fma(lm, pxb, obj);
-            if (tid == 0) {
-                sh.basis[r] = e;   // :196
-                if (k == 0 && it - 1 < d.trace_cap) {
-                    d.trace_enter[it - 1] = e;
-                    d.trace_leave[it - 1] = r;
-                }
-            }
             if (!last) RS_PRICE();
             RS_STAMP(9);
+            RS_MARK_R(14);
             // ---- the entering column has arrived by now: F(i,r), :201 (rows other than r)
             if (want_col) {
                 Spin spin;
@@ -708,20 +825,23 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     }
                     gcol = ld16(cm.r, coff);
                 }
-                l = (PUBL && !from_colS) ? g_f64(gcol) : -g_f64(gcol) / ur;
+                l = (PUBL && !from_colS) ? g_f64(gcol) : -g_f64(gcol) / sh.ctl->ur;
             } else {
-                l = (PUBL && !from_colS) ? lpub : -up / ur;
+                l = (PUBL && !from_colS) ? lpub : -up / sh.ctl->ur;
             }
             xbn = (tid == r) ? xb * inv : fma(l, pxb, xb);
             RS_STAMP(10);
+            RS_MARK_R(15);
             if (!last && jl >= 0) {
                 // the candidate column of the NEXT pivot, updated ahead of the others (same operation,
                 // same operands as the full update below: identical bits)
                 const double t = RS_SLAB_GET(jl);
-                upn = (tid == r) ? t * inv : fma(l, sh.prow[jl], t);
+                upn = (tid == r) ? t * inv : fma(l, lpdev::wave_bcast_f64(pl, jl), t);
             }
         }
-        if (!last) RS_CANDIDATE(upn, xbn);
+        if (!last) {
+            RS_CANDIDATE(upn, xbn);
+        }
         if (!is_comm) {
             // ---- rank-1 update of my registers (tableau_pivot: F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204);
             // the record published above is travelling meanwhile
@@ -735,13 +855,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 } else {
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) Ta[j] = fma(l, sh.prow[j], Ta[j]);
-                }
-            }
-        }
-        if (!last) RS_PUBLISH_COLUMN(upn);
-        if (!is_comm) {
-            if (rowok) {
-                if (tid != r) {
 #pragma unroll
                     for (int j = 0; j < HALF; ++j) Tb[j] = fma(l, sh.prow[HALF + j], Tb[j]);
                 }
@@ -767,6 +880,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     }
                 }
             }
+            if (!last) RS_PUBLISH_COLUMN(upn);
             xb = xbn;
             up = upn;
             RS_STAMP(13);
@@ -816,6 +930,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
 #undef RS_STAMP_R
     if (status == kResidentFailed) {   // nothing is written back: the host reruns on another path
         if (tid == 0) {
+            SimplexState* st = lds_reload(sh.stash).state;
             // first failing workgroup records where it stopped: {code, workgroup, epoch} (diagnostic)
             if (atomicCAS(reinterpret_cast<int*>(rd.comm + rd.abort_off), 0, 1) == 0) {
                 st->enter = sh.ctl->fail * 1000 + k;
@@ -825,31 +940,36 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
         return;
     }
+    if (RS_MARK_A >= 0 && lane == 0 && ((RS_MARK_A < 10 || RS_MARK_A >= 30) ? is_comm : wave == 0)) {
+        v4i g = {(int)(unsigned)mk_acc, (int)(unsigned)(mk_acc >> 32), it, 0};
+        st16(g, cm.r, cm.census + (unsigned)k * 16u, false);
+    }
     if (STAMPS && rd.stamps && (tid == 0 || (is_comm && lane == 0))) {
         const int q0 = is_comm ? 0 : 6, q1 = is_comm ? 6 : 16;
         for (int q = q0; q < q1; ++q) rd.stamps[(size_t)k * 16 + q] = acc[q];
     }
     // ---- write the tableau back (row-major (m+1) x ld, what every other entry point reads)
-    if (rowok) {
-        double* Trow = d.T + (size_t)tid * ld;
+    const SimplexDev de = lds_reload(sh.stash);
+    if (tid < de.m) {
+        double* Trow = de.T + (size_t)tid * de.ld;
 #pragma unroll
         for (int j = 0; j < HALF; ++j) {
-            if (col0 + j < n) Trow[col0 + j] = Ta[j];
-            if (col0 + HALF + j < n) Trow[col0 + HALF + j] = Tb[j];
+            if (col0 + j < de.n) Trow[col0 + j] = Ta[j];
+            if (col0 + HALF + j < de.n) Trow[col0 + HALF + j] = Tb[j];
         }
-        if (k == 0) Trow[n] = xb;
+        if (k == 0) Trow[de.n] = xb;
     }
-    if (wave == 0 && colok) {
-        d.T[(size_t)m * ld + mycol] = dl;
-        d.nonbasic[mycol] = nbl ? 1 : 0;
+    if (wave == 0 && lane < CPT && col0 + lane < de.n) {
+        de.T[(size_t)de.m * de.ld + col0 + lane] = dl;
+        de.nonbasic[col0 + lane] = nbl ? 1 : 0;
     }
     if (k == 0) {
-        for (int i = tid; i < m; i += mpad + 64) d.basis[i] = sh.basis[i];
+        for (int i = tid; i < de.m; i += (int)blockDim.x) de.basis[i] = sh.basis[i];
         if (tid == 0) {
-            d.T[(size_t)m * ld + n] = obj;
-            st->iters = it;
-            st->status = status;
-            st->pivot_valid = 0;
+            de.T[(size_t)de.m * de.ld + de.n] = obj;
+            de.state->iters = it;
+            de.state->status = status;
+            de.state->pivot_valid = 0;
         }
     }
 #undef RS_SLAB_GET
@@ -876,7 +996,7 @@ void launch_resident(const SimplexDev& d, const ResidentDev& rd, size_t shm, hip
             hipLaunchKernelGGL((k_simplex_resident<CPT, NT, ST, PL>), rd.G * rd.stride, rd.mpad + 64, shm, s, d, rd);         \
     } while (0)
     if (stamped)
-        RS_GO(true, true);
+        RS_GO(true, false);
     else if (pubu)
         RS_GO(false, false);
     else
@@ -931,9 +1051,7 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     if (getenv("LP_RESIDENT_FORCE_SC1")) rdv.flags |= 1;     // diagnostics: write-through stores on one XCD too
     if (getenv("LP_RESIDENT_SPREAD")) rdv.stride = 1;        // diagnostics: participants on all XCDs
     if (getenv("LP_RESIDENT_INJECT_FAILURE")) rdv.flags |= 2;   // tests: the census reports a failure
-    if (getenv("LP_RESIDENT_DRAIN")) rdv.flags |= 4;            // experiments
-    if (getenv("LP_RESIDENT_ONESWEEP")) rdv.flags |= 8;
-    const bool pubu = getenv("LP_RESIDENT_PUBU") != nullptr; // A/B: publish u_i (consumers divide)
+    const bool pubu = getenv("LP_RESIDENT_PUBL") == nullptr; // default: publish u_i (consumers divide); A/B: the eta column
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_resident_state_init, 1, 1, 0, s, d, eps, max_iter);
     LP_HIP(ctx, hipMemsetAsync(rd.comm, 0, rd.comm_bytes, s));   // every tag of every granule: epoch 0
@@ -997,6 +1115,21 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
         }
         if (rc >= 0 && stats) stats->solve_ms += ms;   // the caller waited for the timed-out launch too
         return rc;
+    }
+    if (RS_MARK_A >= 0 && getenv("LP_RESIDENT_MARKS")) {   // diagnostic builds: the interval RS_MARK_A -> RS_MARK_B per workgroup
+        std::vector<int> cg((size_t)rd.G * 4);
+        if (hipMemcpy(cg.data(), rd.comm + rd.census_off, cg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum = 0, mx = 0;
+            for (int q = 0; q < rd.G; ++q) {
+                const double c = (double)(((unsigned long long)(unsigned)cg[q * 4 + 1] << 32) | (unsigned)cg[q * 4]) /
+                                 (double)(cg[q * 4 + 2] > 0 ? cg[q * 4 + 2] : 1);
+                sum += c;
+                mx = c > mx ? c : mx;
+            }
+            fprintf(stderr, "[resident marks] %d -> %d: workgroup 0 %.0f, mean %.0f, max %.0f cycles per pivot\n", RS_MARK_A, RS_MARK_B,
+                    (double)(((unsigned long long)(unsigned)cg[1] << 32) | (unsigned)cg[0]) / (double)(cg[2] > 0 ? cg[2] : 1),
+                    sum / rd.G, mx);
+        }
     }
     p->last_status = status;
     p->last_iters = p->h_state->iters;

@@ -83,11 +83,11 @@ def test_baseline_config_512x1024(ctx, algo):
     np.testing.assert_allclose(A @ xfull, b, rtol=1e-9)
 
 
-@pytest.mark.parametrize("mode", ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_PUBU"])
+@pytest.mark.parametrize("mode", ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_PUBL"])
 def test_baseline_config_512x1024_resident_modes(ctx, monkeypatch, mode):
     """The chip-resident kernel's placement-dependent forms, forced: participants spread over all
     XCDs (write-through stores, no shared L2), write-through stores on one XCD, and the A/B form that
-    publishes the candidate column itself instead of its eta column.  Same bits as the oracle."""
+    publishes the eta column instead of the candidate column itself.  Same bits as the oracle."""
     monkeypatch.setenv(mode, "1")
     m, n = 512, 1024
     A, b, c, basis = lpcases.random_lp(0, m, n)
@@ -96,10 +96,11 @@ def test_baseline_config_512x1024_resident_modes(ctx, monkeypatch, mode):
     _assert_bit_exact(g, r)
 
 
-@pytest.mark.parametrize("seed,m,n", [(41, 768, 1536), (42, 600, 1300), (43, 1024, 2048), (44, 513, 700)])
+@pytest.mark.parametrize("seed,m,n", [(41, 768, 1536), (42, 600, 1300), (43, 960, 1920), (44, 513, 700)])
 def test_resident_rows_beyond_512(ctx, seed, m, n):
-    """512 < m <= 1024: 16 columns per workgroup, up to 1024 threads (one row per thread), workgroups
-    on several XCDs.  AUTO picks the chip-resident algorithm for these shapes too."""
+    """512 < m <= 960: 16 columns per workgroup, up to 960 row threads (one row per thread) plus the
+    communication wave, workgroups on several XCDs.  AUTO picks the chip-resident algorithm for these
+    shapes too."""
     A, b, c, basis = lpcases.random_lp(seed, m, n)
     r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
     assert r["status"] == o.OPTIMAL and r["iters"] > 50
@@ -107,6 +108,21 @@ def test_resident_rows_beyond_512(ctx, seed, m, n):
         g = _run(ctx, A, b, c, basis, True, n - m, algo=algo)
         assert g["algo_used"] == capi.SIMPLEX_RESIDENT
         _assert_bit_exact(g, r)
+
+
+def test_resident_shape_limit(ctx):
+    """m > 960 does not fit (one row per thread + the communication wave <= 1024 threads): an explicit
+    request says so, AUTO solves it on the look-ahead path, same bits as the oracle."""
+    m, n = 1024, 1200
+    A, b, c, basis = lpcases.random_lp(46, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=1 << 14, want_tableau=True)
+    p = ctx.simplex_problem(A, b, c, basis, True, n - m)
+    with pytest.raises(capi.LPError):
+        p.run(algo=capi.SIMPLEX_RESIDENT)
+    p.free()
+    g = _run(ctx, A, b, c, basis, True, n - m, algo=capi.SIMPLEX_AUTO)
+    assert g["algo_used"] == capi.SIMPLEX_LOOKAHEAD
+    _assert_bit_exact(g, r)
 
 
 def test_resident_fallback_is_visible(ctx, monkeypatch):
