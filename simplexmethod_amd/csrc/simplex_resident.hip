@@ -133,6 +133,7 @@ struct Shared {
     Ctl* ctl;
     v4i* pub;        // {epoch, u_r.lo, epoch, u_r.hi} of my candidate, from the communication wave
     int* basis;      // mpad      : N by position (every workgroup keeps its own copy)
+    double* mirror;  // mpad x (CPT + 2): row-readable copy of the register slab (+ xB), see RS_MIRROR_WRITE
     SimplexDev* stash;   // the kernel's arguments for the epilogue: re-read from here, the pivot loop is ~100 SGPRs
                          // short and every uniform value kept live across it is reloaded by v_readlane chains
 };
@@ -151,20 +152,21 @@ __device__ __forceinline__ T lds_reload(const T* p) {
 
 __host__ __device__ inline size_t resident_lds_bytes(int mpad, int cpt) {
     return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + 2048 /* SelScratch */ + sizeof(Ctl) + 16 +
-           sizeof(int) * (size_t)mpad + 256 /* stash */;
+           sizeof(int) * (size_t)mpad + 256 /* stash */ + sizeof(double) * (size_t)mpad * ((size_t)cpt + 2) /* mirror */;
 }
 
 // Read of the decision block's head {mode, kst, e, r} and of the failure flag (the pivot element and the
 // scan value are read where the rare paths need them)
 __device__ __forceinline__ Ctl ctl_read_head(const Ctl* p) {
     const v4i a = *reinterpret_cast<const v4i*>(p);
+    const double ur = p->ur, dE = p->dE;
     const int f = p->fail;
     Ctl o;
     o.mode = __builtin_amdgcn_readfirstlane(a.x);
     o.kst = __builtin_amdgcn_readfirstlane(a.y);
     o.e = __builtin_amdgcn_readfirstlane(a.z);
     o.r = __builtin_amdgcn_readfirstlane(a.w);
-    o.ur = 0.0; o.dE = 0.0;
+    o.ur = ur; o.dE = dE;   // (per-lane copies of wave-uniform values: they feed vector arithmetic only)
     o.fail = __builtin_amdgcn_readfirstlane(f);
     o.plain = 0; o.pad0 = 0; o.pad1 = 0;
     return o;
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     sh.stash = reinterpret_cast<SimplexDev*>(sh.basis + mpad);
     static_assert(sizeof(SimplexDev) <= 256, "resident_lds_bytes reserves 256 bytes for the stash");
     if (tid == 0) *sh.stash = d;
+    sh.mirror = reinterpret_cast<double*>(reinterpret_cast<char*>(sh.stash) + 256);
+    constexpr int MS = CPT + 2;   // row stride of the mirror in doubles (16-byte rows; 272 / 144 bytes: b128 stores conflict-free)
 
     Comm cm;
     cm.r = __builtin_amdgcn_make_buffer_rsrc(rd.comm, 0, rd.comm_bytes, 0x00020000);
@@ -250,6 +254,23 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     // indexed register move for a wave-uniform dynamic column, no select chain and no scratch)
     vslab Ta, Tb;
 #define RS_SLAB_GET(j) (((j) < HALF) ? Ta[(j) & (HALF - 1)] : Tb[(j) & (HALF - 1)])
+    // The LDS mirror: every row thread keeps a copy of its row (CPT entries + xB) where the OTHER waves can read
+    // it.  After a decision every wave takes its pivot-row entries straight from row r of the mirror — no staging
+    // by the row's owner, no barrier in front of the pricing.  Written behind the rank-1 update, i.e. while the
+    // records travel; read only between the decision barrier and the ratio barrier.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+#define RS_MIRROR_WRITE()                                                                  \
+    do {                                                                                   \
+        if (!is_comm) {                                                                    \
+            double* mr_ = sh.mirror + (size_t)tid * MS;                                    \
+            _Pragma("unroll") for (int j = 0; j < HALF; j += 2) {                           \
+                const v2d a_ = {Ta[j], Ta[j + 1]}, b_ = {Tb[j], Tb[j + 1]};                \
+                *reinterpret_cast<v2d*>(mr_ + j) = a_;                                     \
+                *reinterpret_cast<v2d*>(mr_ + HALF + j) = b_;                              \
+            }                                                                              \
+            mr_[CPT] = xb;                                                                 \
+        }                                                                                  \
+    } while (0)
     {
         const double* Trow = d.T + (size_t)(rowok ? tid : 0) * ld;
 #pragma unroll
@@ -259,6 +280,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
     }
     double xb = rowok ? d.T[(size_t)tid * ld + n] : 0.0;   // replica of column n
+    RS_MIRROR_WRITE();   // (visible to the other waves behind the census barrier)
     // reduced costs of this workgroup's columns: lane l of EVERY row wave holds column col0 + l
     const int mycol = col0 + lane;
     const bool colok = lane < CPT && mycol < n;
@@ -363,27 +385,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         jl = hit ? (int)__builtin_ctzll(hit) : -1;                                 \
     } while (0)
 
-    // my part of the pivot row (before scaling) and xB_r, broadcast through LDS by the thread that owns row RR
-#define RS_STAGE_PROW(RR)                                     \
-    do {                                                      \
-        if (tid == (RR)) {                                    \
-            _Pragma("unroll") for (int j = 0; j < HALF; ++j) { \
-                sh.prow[j] = Ta[j];                           \
-                sh.prow[HALF + j] = Tb[j];                    \
-            }                                                 \
-            sh.prow[CPT] = xb;                                \
-        }                                                     \
-    } while (0)
-    // the two wave-uniform quotients of the update, by the communication wave: F(r,r) = 1/u_r (:204) and the
-    // reduced-cost row's -d_e/u_r (two divisions off every row wave's path); they travel with the pivot row
-#define RS_QUOTIENTS(UR, DE)                                                    \
-    do {                                                                        \
-        if (lane == 0) {                                                        \
-            sh.prow[CPT + 1] = 1.0 / (UR);                                      \
-            sh.prow[CPT + 2] = -(maximize ? (DE) : -(DE)) / (UR);               \
-        }                                                                       \
-    } while (0)
-
     // Candidate (column values UP for the rows, xB values XBV).  Row waves: first half of the ratio test
     // (:181-192; every wave leaves the summary of its 64 rows in LDS), wave 0 adds the pricing summary.
     // A barrier.  The communication wave finishes the ratio test and publishes the record {M_k, column,
@@ -433,6 +434,10 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         RS_MARK_R(17);                                                                               \
         RS_MARK_C(5);                                                                                \
         if (is_comm) {                                                                               \
+            if (lane == 0 && bk_r >= 0) {   /* N(leave_pos) = enter, :196: every row wave has read the old entry */ \
+                sh.basis[bk_r] = bk_e;                                                               \
+                bk_r = -1;                                                                           \
+            }                                                                                        \
             const int pJ_ = sh.sel->pJ;                                                              \
             const int pOk_ = sh.sel->pOk;                                                            \
             const unsigned long long pM_ = sh.sel->pM;                                               \
@@ -504,21 +509,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     } while (0)
 
     int bk_e = -1, bk_r = -1;
-    // bookkeeping of the communication wave, off everybody's path
-#define RS_BOOKKEEP()                                                                                   \
-    do {                                                                                                \
-        if (is_comm && lane == 0 && bk_r >= 0) {                                                        \
-            sh.basis[bk_r] = bk_e;                                                                      \
-            if (k == 0) {   /* (workgroup 0 only: the trace pointers come from the stash, not from SGPRs held all along) */ \
-                const SimplexDev dt = lds_reload(sh.stash);                                             \
-                if (it - 1 < dt.trace_cap) {                                                            \
-                    dt.trace_enter[it - 1] = bk_e;                                                      \
-                    dt.trace_leave[it - 1] = bk_r;                                                      \
-                }                                                                                       \
-            }                                                                                           \
-            bk_r = -1;                                                                                  \
-        }                                                                                               \
-    } while (0)
     double up = 0.0;
     if (status == kRunning) {   // prologue: candidate of the initial tableau
         if (!is_comm) {
@@ -776,16 +766,9 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         v4i gcol = {0, 0, 0, 0};
         const unsigned ep_col = ep;
         if (want_col) gcol = ld16(cm.r, coff);   // awaited after the next pricing
-        // ---- my part of the pivot row (before scaling) through LDS, by its owner; the communication wave
-        // (idle until the ratio barrier) adds the two quotients of the update meanwhile
-        if (is_comm)
-            RS_QUOTIENTS(sh.ctl->ur, sh.ctl->dE);
-        else
-            RS_STAGE_PROW(r);
-        const int oldb = sh.basis[r];    // (rewritten by the communication wave behind a later barrier)
+        const int oldb = sh.basis[r];    // (rewritten by the communication wave behind the ratio barrier)
         RS_STAMP_R(7);
         RS_MARK_R(12);
-        __syncthreads();   // the pivot-row barrier
         RS_STAMP_R(8);
         RS_MARK_C(4);
         RS_MARK_R(13);
@@ -793,19 +776,29 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         const bool last = it >= max_iter;   // :450: this pivot is applied, no further one is chosen
         double xbn = 0.0, upn = 0.0, l = 0.0, inv = 0.0;
         if (is_comm) {
-            // N(leave_pos) = enter (:196) and the trace, in this wave's idle window (it has nothing to do until the
-            // ratio barrier) and behind the pivot-row barrier: every row wave has read the old basis entry
+            // this wave's idle window (nothing to do until the ratio barrier): the pivot row goes from the mirror
+            // to the place the rows' rank-1 update reads it from — thread r overwrites its mirror row during that
+            // update — and the trace is kept
+            if (lane <= CPT) sh.prow[lane] = sh.mirror[(size_t)r * MS + lane];
             bk_e = e;
             bk_r = r;
-            RS_BOOKKEEP();
+            if (k == 0 && lane == 0) {   // (workgroup 0 only: the trace pointers come from the stash, not from SGPRs held all along)
+                const SimplexDev dt = lds_reload(sh.stash);
+                if (it - 1 < dt.trace_cap) {
+                    dt.trace_enter[it - 1] = e;
+                    dt.trace_leave[it - 1] = r;
+                }
+            }
         } else {
             // ---- reduced-cost row (row m of the tableau) after this pivot, replicated per wave.  ONE LDS read
-            // per wave: lane j takes pivot-row entry j (lane CPT: xB_r); the two wave-uniform entries needed
-            // below (xB_r and the candidate's) come out of these registers by v_readlane
-            const double pl = sh.prow[lane <= CPT + 2 ? lane : 0];
+            // per wave, straight from row r of the mirror: lane j takes pivot-row entry j (lane CPT: xB_r); the
+            // wave-uniform entries needed below (xB_r and the candidate's) come out of these registers by
+            // v_readlane.  The two quotients of the update, F(r,r) = 1/u_r (:204) and the reduced-cost row's
+            // -d_e/u_r, are computed while that read is in flight.
+            const double pl = sh.mirror[(size_t)r * MS + (lane <= CPT ? lane : 0)];
+            inv = 1.0 / cc.ur;
+            const double lm = -(maximize ? cc.dE : -cc.dE) / cc.ur;
             const double pxb = lpdev::wave_bcast_f64(pl, CPT);
-            inv = lpdev::wave_bcast_f64(pl, CPT + 1);
-            const double lm = lpdev::wave_bcast_f64(pl, CPT + 2);
             if (colok) {
                 dl = (mycol == e) ? 0.0 : fma(lm, pl, dl);
                 if (mycol == e) nbl = false;
@@ -883,6 +876,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             if (!last) RS_PUBLISH_COLUMN(upn);
             xb = xbn;
             up = upn;
+            RS_MIRROR_WRITE();
             RS_STAMP(13);
         }
         if (last) status = LP_ITER_LIMIT;
@@ -896,6 +890,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     // failed anywhere — also one whose entering column timed out on the very last pivot — raises the
     // abort word instead, which every spin of the others observes; nobody writes anything back then.
     __syncthreads();   // (a row thread's late fail = 5 is visible to everyone below)
+    if (is_comm && lane == 0 && bk_r >= 0) sh.basis[bk_r] = bk_e;   // (the last pivot before the iteration limit)
+    __syncthreads();
     if (status != kResidentFailed && sh.ctl->fail) status = kResidentFailed;
     if (status != kResidentFailed) {
         ++ep;
