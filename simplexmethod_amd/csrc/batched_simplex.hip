@@ -113,12 +113,16 @@ __device__ __forceinline__ int wave_ratio_select(const double (&rv)[K], int m, d
     double lext = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) lext = fmin(lext, rv[k]);
-    const double M = lpdev::f64_from_key(lpdev::wave_ext_key<false>(lpdev::f64_sort_key(lext)));   // (fmin dropped NaNs)
+    // (short-cut reductions of device_select.hpp: one 6-step pass over the high words; when a single lane
+    // holds the extreme — the common case — its low word and its index come by v_readlane instead of two more passes)
+    unsigned long long hit;
+    const double M = lpdev::f64_from_key(lpdev::wave_ext_key_n<false, 64>(lpdev::f64_sort_key(lext), &hit));   // (fmin dropped NaNs)
     if (!(M < INFINITY)) return -1;
     int lidx = INT_MAX;
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) lidx = (rv[k] == M && lane + 64 * k < m) ? lane + 64 * k : lidx;
-    const int jM = (int)lpdev::wave_ext_u32<false>((unsigned)lidx);
+    const int jM = ((hit & (hit - 1)) == 0ULL) ? __builtin_amdgcn_readlane(lidx, (int)__builtin_ctzll(hit))
+                                               : (int)lpdev::wave_ext_u32<false>((unsigned)lidx);
     double lp = INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) lp = (lane + 64 * k < jM) ? fmin(lp, rv[k]) : lp;
@@ -373,12 +377,22 @@ __device__ __forceinline__ int wave_price_select(const double (&dv)[K], const in
             lslot = lane + 64 * q;
         }
     }
-    const double M = lpdev::f64_from_key(lpdev::wave_ext_key<WANT_MAX>(lpdev::f64_sort_key(lv)));
-    const int jM = (int)lpdev::wave_ext_u32<false>((unsigned)((lv == M && lv != sentinel) ? lkey : INT_MAX));
+    // (short-cut reductions: one pass over the high words of the keys; a single lane holding the extreme gives
+    // its variable index and slot by v_readlane — two six-step passes fewer than reducing value, then index)
+    unsigned long long hits;
+    const double M = lpdev::f64_from_key(lpdev::wave_ext_key_n<WANT_MAX, 64>(lpdev::f64_sort_key(lv), &hits));
     best = sentinel;
+    if (M == sentinel) return -1;
+    int jM, src;
+    if ((hits & (hits - 1)) == 0ULL) {
+        src = (int)__builtin_ctzll(hits);
+        jM = __builtin_amdgcn_readlane(lkey, src);
+    } else {
+        jM = (int)lpdev::wave_ext_u32<false>((unsigned)(lv == M ? lkey : INT_MAX));
+        src = (int)__builtin_ctzll(__ballot(lv == M && lkey == jM));
+    }
     if (jM == INT_MAX) return -1;
-    const unsigned long long hit = __ballot(lv == M && lkey == jM);
-    const int sM = __builtin_amdgcn_readlane(lslot, (int)__builtin_ctzll(hit));
+    const int sM = __builtin_amdgcn_readlane(lslot, src);
     double lp = sentinel;
 #pragma unroll
     for (int q = 0; q < K; ++q)
@@ -423,6 +437,15 @@ __device__ __forceinline__ int wave_price_select(const double (&dv)[K], const in
 // ---------------------------------------------------------------------------------------------
 // Rows are padded to G * RPT: entries past m hold zeros in the eta column (fma(0, p, 0) = 0), so the
 // per-row loops carry no predicates (44 live lane masks would spill ~600 SGPRs).
+// Staging area of the initial tableau (register form): columns of A are read whole and coalesced (a column is
+// m contiguous doubles), CH at a time, into LDS with an odd row stride, and every updating thread takes its rows
+// from there — its own 43 reads straight from A were 64 different cache lines per instruction.
+__host__ __device__ inline int batched_stage_stride(int m) { return m | 1; }
+__host__ __device__ inline int batched_stage_cols(int m) {
+    const int ch = 4096 / batched_stage_stride(m);   // <= 32 KB
+    return ch < 1 ? 1 : (ch > 32 ? 32 : ch);
+}
+
 template <int NT>
 __host__ __device__ inline int batched_reg_rpt(int m, int n) {   // rows per updating thread, 0 = does not fit
     const int W = n - m + 1;
@@ -481,10 +504,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
         posofvar[bin[q]] = q;
     }
     __syncthreads();
-    if (tid == 0) {  // slots take the non-basic variables in ascending order
+    if (tid < 64) {  // slots take the non-basic variables in ascending order (wave 0: ballot compaction)
         int s = 0;
-        for (int q = 0; q < n; ++q)
-            if (posofvar[q] < 0) slotvar[s++] = q;
+        for (int base = 0; base < n; base += 64) {
+            const int q = base + tid;
+            const bool nb = q < n && posofvar[q] < 0;
+            const unsigned long long mask = __ballot(nb);
+            if (nb) slotvar[s + __popcll(mask & ((1ULL << tid) - 1ULL))] = q;
+            s += __popcll(mask);
+        }
     }
     __syncthreads();
     // updating threads: tid >= 64; column j, row group g of G; rows g*RPT .. g*RPT + RPT-1 (a contiguous
@@ -495,10 +523,29 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
     const int g = ut >= 0 ? ut / W : G;
     const bool upd = ut >= 0 && g < G;
     double t[RPT];
+    {
+        double* stage = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(posofvar + n) + 15) & ~(uintptr_t)15);
+        const int SP = batched_stage_stride(m), CH = batched_stage_cols(m);
+        for (int c0 = 0; c0 < W; c0 += CH) {
+            for (int e = tid; e < CH * m; e += NT) {   // coalesced along the rows of a column
+                const int cc = e / m, i = e - cc * m;
+                if (c0 + cc < W) stage[cc * SP + i] = (c0 + cc < nn) ? A[(size_t)slotvar[c0 + cc] * m + i] : b[i];
+            }
+            __syncthreads();
+            if (upd && j >= c0 && j < c0 + CH) {
+                const double* col = stage + (j - c0) * SP;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int i = g * RPT + k;
-        t[k] = (upd && i < m) ? ((j < nn) ? A[(size_t)slotvar[j] * m + i] : b[i]) : 0.0;
+                for (int k = 0; k < RPT; ++k) {
+                    const int i = g * RPT + k;
+                    t[k] = i < m ? col[i] : 0.0;
+                }
+            }
+            __syncthreads();
+        }
+        if (!upd) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) t[k] = 0.0;
+        }
     }
     for (int q = tid; q < mp; q += NT) {
         xcol[q] = q < m ? b[q] : 0.0;
@@ -534,7 +581,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
     auto price = [&]() {
         double best;
         int se0;
-        if (dreg) {
+        if (dreg && nn <= 128) {   // (two entries per lane: half of the four-per-lane form's work)
+            const double dv2[2] = {dv[0], dv[1]};
+            const int kv2[2] = {kv[0], kv[1]};
+            se0 = d.maximize ? wave_price_select<true, 2>(dv2, kv2, eps, best)
+                             : wave_price_select<false, 2>(dv2, kv2, eps, best);
+        } else if (dreg) {
             se0 = d.maximize ? wave_price_select<true, 4>(dv, kv, eps, best)
                              : wave_price_select<false, 4>(dv, kv, eps, best);
         } else {
@@ -636,9 +688,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 break;
             }
             // ---- this wave's share of the eta column (:198-204)
+            // (one division per entry: F(r,r) = 1/u_r and F(i,r) = -u_i/u_r share the divisor, :201-204)
             const double ur = ucol[r];
-            const double inv = 1.0 / ur;
-            for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = ((i == r) ? 1.0 : -ucol[i]) / ur;
             if (tid == 0) lcol[mp] = -drow[se] / ur;
             BR_STAMP(4);
             __syncthreads();   // (4) eta column and pivot row complete
@@ -649,6 +701,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             if (dreg) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (q >= 2 && nn <= 128) break;   // (uniform: entries 128.. do not exist)
                     const int sl = lane + 64 * q;
                     if (sl < nn) {
                         dv[q] = (sl == se) ? lm : fma(lm, prow[sl], dv[q]);
@@ -704,9 +757,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 break;
             }
             // ---- eta column (:198-204) and the pivot row, from the owners' registers
+            // (one division per entry: F(r,r) = 1/u_r and F(i,r) = -u_i/u_r share the divisor, :201-204)
             const double ur = ucol[r];
-            const double inv = 1.0 / ur;
-            for (int i = tid; i < m; i += NT) lcol[i] = (i == r) ? inv : -ucol[i] / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = ((i == r) ? 1.0 : -ucol[i]) / ur;
             const int gr = r / RPT, kr = r % RPT;
             if (upd && g == gr) {
                 // (kr is uniform: a switch reaches the one row with a scalar branch tree — 44 predicated
@@ -780,6 +833,7 @@ static int batched_reg_launch(lp_context* ctx, const BatchedDev& d) {
     const size_t dbl = sizeof(Published) / 8 + 2 * (size_t)W + (size_t)(mp + 1) + 2 * (size_t)mp;
     size_t shm = dbl * 8 + sizeof(int) * (size_t)(nn + d.m + d.n);
     shm = (shm + 15) & ~(size_t)15;
+    shm += 16 + sizeof(double) * (size_t)batched_stage_cols(d.m) * (size_t)batched_stage_stride(d.m);   // staging of the initial tableau
     LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG, STAMPS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG, STAMPS>), d.batch, NT, shm, ctx->stream, d);
