@@ -122,23 +122,18 @@ def pivot_leg(ctx, args):
         look = best_of(capi.SIMPLEX_LOOKAHEAD, 3)
     except capi.LPError:
         look = None
-    # per-phase cycle sums of the chip-resident kernel (diagnostic instantiation: ~20 % slower than the
-    # product kernel, so only the SHARES are meaningful; workgroup 0, summed over the solve)
+    # where a pivot of the chip-resident kernel goes: interval timings of diagnostic builds (two clock reads per
+    # pivot each: scripts/resident_marks.py), committed with the hash of the kernel sources they were taken on
     phases = None
-    if resident:
-        import ctypes as C
-        ctx.lib.lp_debug_simplex_stamps(p.h, 16, None)          # turns the instrumented instantiation on
-        for _ in range(3):   # (the first launch of the instrumented instantiation pays its code load)
-            p.reset()
-            rc_s, st_s = p.run(algo=args.simplex_algo)
-        buf = (C.c_ulonglong * 16)()
-        ctx.lib.lp_debug_simplex_stamps(p.h, 1, buf)
-        names = capi.RESIDENT_STAMP_NAMES
-        cyc = [buf[i] / max(st_s.pivots, 1) for i in range(16)]
-        tot = sum(cyc[:5])      # the communication wave's loop = the pivot's critical path
-        phases = {"instrumented_solve_ms": round(st_s.solve_ms, 3), "cycles_per_pivot_total": round(tot, 1),
-                  "cycles_per_pivot": {k: round(v, 1) for k, v in zip(names, cyc)},
-                  "hop_share_of_pivot": round(cyc[0] / tot, 4) if tot else None}
+    if resident and (m, n) == (512, 1024):
+        try:
+            mk = json.load(open(os.path.join(ROOT, "profiles", "r03_resident_marks.json")))
+            if mk.get("kernel_source_hash") == kernel_source_hash():
+                phases = {"source": "profiles/r03_resident_marks.json (scripts/resident_marks.py)",
+                          "cycles_per_pivot_mean_over_workgroups": mk["intervals"],
+                          "critical_path_cycles_per_pivot": mk.get("critical_path_cycles_per_pivot")}
+        except Exception:
+            phases = None
     p.reset()
     upd1_ms = min(p.bench_update(0, 0, 200) for _ in range(3))   # ms per rank-1 update launch
     try:   # rank-J update alone: 200 back-to-back launches between two events
@@ -167,8 +162,7 @@ def pivot_leg(ctx, args):
         "one_shot_host_buffers_ms": round(1e3 * t_one, 3),
         "budget_us_per_pivot_at_70pct_of_8TBs": round(bytes_per_pivot / (0.7 * HBM_PEAK_GBS * 1e9) * 1e6, 3),
     }
-    if phases is not None:
-        out["resident_kernel_phases_workgroup0"] = phases
+    out["resident_kernel_intervals"] = phases   # null unless the committed marks belong to these kernel sources
     if look is not None:
         out["lookahead_path_solve_ms"] = round(look["solve_ms"], 3)
         out["lookahead_path_us_per_pivot"] = round(1e3 * look["solve_ms"] / max(look["pivots"], 1), 3)

@@ -14,9 +14,7 @@ import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 0), (0, 0),
-         (10, 11), (11, 12), (12, 13), (13, 14), (14, 15), (15, 16), (16, 17), (17, 18), (18, 19), (19, 20), (20, 10),
-         (5, 30), (30, 31), (31, 32), (32, 6), (1, 34), (34, 2)]
+PAIRS = [(0, 1), (1, 2), (2, 3), (3, 5), (5, 6), (6, 0), (10, 11), (11, 14), (14, 15), (15, 16), (17, 20), (20, 10)]
 if os.environ.get("LP_MARK_PAIRS"):   # e.g. LP_MARK_PAIRS=5-30,30-31
     PAIRS = [tuple(int(v) for v in t.split("-")) for t in os.environ["LP_MARK_PAIRS"].split(",")]
 AB = os.path.join(ROOT, "ab_libs")
@@ -44,7 +42,20 @@ def build():
             print("built", lib, flush=True)
 
 
+NAMES = {(0, 1): "comm: poll until all records are fresh (the hop)", (1, 2): "comm: decide, write the decision block",
+         (2, 3): "comm: decision barrier", (3, 5): "comm: waits for the rows (decision read, mirror row, quotients, pricing, ratio slices, ratio barrier)",
+         (5, 6): "comm: ratio stage 2, record out", (6, 0): "comm: loop",
+         (10, 11): "rows: read the decision block", (11, 14): "rows: column request, pivot-row entries from the mirror, two quotients, reduced costs, pricing",
+         (14, 15): "rows: entering column arrived, eta entry", (15, 16): "rows: candidate column, ratio, slice summary",
+         (17, 20): "rows: rank-1 update, mirror write", (20, 10): "rows: wait for the next decision"}
+
+
 def run():
+    import json, re
+    import bench
+    out = {"kernel_source_hash": bench.kernel_source_hash(), "workload": "m=512 n=1024 seed 0, 345 pivots, default form",
+           "what": "cycles per pivot between two marks of the communication wave (marks 0-9) or of row wave 0 (10-29), mean over "
+                   "the workgroups; each interval from its own diagnostic build (two clock reads per pivot)", "intervals": {}}
     code = ("import os,sys; sys.path.insert(0, %r); from simplexmethod_amd import capi; ctx = capi.Context(0); "
             "A,b,c,basis = capi.gen_lp(0,512,1024); p = ctx.simplex_problem(A,b,c,basis,True,512); "
             "[ (p.reset(), p.run(algo=capi.SIMPLEX_RESIDENT)) for _ in range(3)]; os.environ['LP_RESIDENT_MARKS']='1'; "
@@ -52,7 +63,17 @@ def run():
     for a, c in PAIRS:
         env = dict(os.environ, LP_LIB_PATH=os.path.join(AB, "libmarks_%d_%d.so" % (a, c)), LP_RESIDENT_STRICT="1")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
-        print("%2d -> %2d: %s | %s" % (a, c, (r.stderr.strip().splitlines() or ["?"])[-1], r.stdout.strip()), flush=True)
+        last = (r.stderr.strip().splitlines() or ["?"])[-1]
+        print("%2d -> %2d: %s | %s" % (a, c, last, r.stdout.strip()), flush=True)
+        mm = re.search(r"mean (\d+)", last)
+        if mm:
+            out["intervals"]["%d->%d %s" % (a, c, NAMES.get((a, c), ""))] = int(mm.group(1))
+    comm = [v for k2, v in out["intervals"].items() if int(k2.split("->")[0]) < 10]
+    out["critical_path_cycles_per_pivot"] = sum(comm) if comm else None
+    path = os.path.join(ROOT, "gpurun_out", "resident_marks.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(out, open(path, "w"), indent=1)
+    print("wrote", path)
 
 
 if __name__ == "__main__":
