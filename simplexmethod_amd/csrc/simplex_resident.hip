@@ -150,9 +150,12 @@ __device__ __forceinline__ T lds_reload(const T* p) {
     return out;
 }
 
-__host__ __device__ inline size_t resident_lds_bytes(int mpad, int cpt) {
-    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)mpad) + 2048 /* SelScratch */ + sizeof(Ctl) + 16 +
-           sizeof(int) * (size_t)mpad + 256 /* stash */ + sizeof(double) * (size_t)mpad * ((size_t)cpt + 2) /* mirror */;
+// LDS layout: every array at an offset that depends only on the kernel's template parameters (the arrays are
+// sized for the instantiation's largest row count NT: the workgroup has the CU to itself anyway), so that every
+// LDS address in the pivot loop is an immediate and none of the nine base pointers occupies an SGPR
+__host__ __device__ constexpr size_t resident_lds_bytes(int nt, int cpt) {
+    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)nt) + 2048 /* SelScratch */ + sizeof(Ctl) + 16 +
+           sizeof(int) * (size_t)nt + 256 /* stash */ + sizeof(double) * (size_t)nt * ((size_t)cpt + 2) /* mirror */;
 }
 
 // Read of the decision block's head {mode, kst, e, r} and of the failure flag (the pivot element and the
@@ -232,12 +235,12 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     Shared sh;
     sh.prow = smem;
     sh.ratio = sh.prow + CPT + 8;
-    sh.u = sh.ratio + mpad;
-    sh.sel = reinterpret_cast<SelScratch*>(sh.u + mpad);
-    sh.ctl = reinterpret_cast<Ctl*>(sh.sel + 1);
+    sh.u = sh.ratio + NT;
+    sh.sel = reinterpret_cast<SelScratch*>(sh.u + NT);
+    sh.ctl = reinterpret_cast<Ctl*>(reinterpret_cast<char*>(sh.sel) + 2048);
     sh.pub = reinterpret_cast<v4i*>(sh.ctl + 1);
     sh.basis = reinterpret_cast<int*>(sh.pub + 1);
-    sh.stash = reinterpret_cast<SimplexDev*>(sh.basis + mpad);
+    sh.stash = reinterpret_cast<SimplexDev*>(sh.basis + NT);
     static_assert(sizeof(SimplexDev) <= 256, "resident_lds_bytes reserves 256 bytes for the stash");
     if (tid == 0) *sh.stash = d;
     sh.mirror = reinterpret_cast<double*>(reinterpret_cast<char*>(sh.stash) + 256);
@@ -1040,7 +1043,7 @@ int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_
     hipStream_t s = ctx->stream;
     if (rd.G < 1 || !rd.comm) LP_FAIL(ctx, LP_BAD_ARG, "chip-resident path unavailable for this problem");
     // > 80 KiB of LDS per workgroup: one workgroup per CU, so that G workgroups own G CUs
-    size_t shm = resident_lds_bytes(rd.mpad, rd.cpt);
+    size_t shm = resident_lds_bytes(rd.cpt == 32 ? 512 : 960, rd.cpt);   // (the instantiation's NT: see resident_lds_bytes)
     if (shm < 84 * 1024) shm = 84 * 1024;
     const bool stamped = rd.stamps != nullptr;
     ResidentDev rdv = rd;
