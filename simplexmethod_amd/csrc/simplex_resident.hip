@@ -112,6 +112,12 @@ __device__ __forceinline__ v4i lds_granules(const v4i* p) {
     return g;
 }
 
+// Workgroup barrier of the pivot loop: LDS traffic only.  __syncthreads() also waits for the wave's GLOBAL memory
+// operations (vmcnt(0): its fence has workgroup scope) — at the ratio barrier that was the acknowledgement of every
+// row wave's column store (~400 cycles), at the decision barrier the communication wave's sweep still in flight
+// (~200) — and nothing in the loop passes data between the waves of a workgroup through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Bounded spin bookkeeping: cheap until 256 polls have failed, then the real-time clock decides.
 struct Spin {
     unsigned n = 0;
@@ -400,7 +406,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         slot = par * (unsigned)G + (unsigned)k;                                                      \
         if (!is_comm) {                                                                              \
             if (jl >= 0) {                                                                           \
-                if (!PUBL && rowok) st16(g_pack(ep, (UP)), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
                 const double ratio_ = (rowok && (UP) > eps) ? nan_to((XBV) / (UP), INFINITY) : INFINITY;   /* :185-186 */ \
                 sh.ratio[tid] = ratio_;                                                              \
                 sh.u[tid] = (UP);                                                                    \
@@ -428,11 +433,14 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     sh.sel->pOk = okp_ ? 1 : 0;                                                      \
                 }                                                                                    \
             }                                                                                        \
+            /* the candidate column for the others goes out LAST: a store in front of the ratio test made the      \
+               compiler wait for its completion (vmcnt(0), ~400 cycles) before it reused the store's registers */ \
+            if (!PUBL && jl >= 0 && rowok) st16(g_pack(ep, (UP)), cm.r, cm.col + slot * col_stride + (unsigned)tid * 16u, plain); \
         }                                                                                            \
         RS_STAMP_R(11);                                                                              \
         RS_STAMP_C(2);                                                                               \
         RS_MARK_R(16);                                                                               \
-        __syncthreads();                                                                             \
+        lds_barrier();                                                                               \
         RS_STAMP_R(12);                                                                              \
         RS_MARK_R(17);                                                                               \
         RS_MARK_C(5);                                                                                \
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             RS_STAMP(1);
             RS_MARK_C(2);
         }
-        __syncthreads();   // the decision barrier
+        lds_barrier();   // the decision barrier
         RS_STAMP_R(6);
         RS_MARK_C(3);
         RS_MARK_R(10);
