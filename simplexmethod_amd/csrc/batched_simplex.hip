@@ -27,6 +27,18 @@ namespace {
 
 constexpr int kRunning = -100;
 
+// Uncached-by-the-compiler LDS word accesses for the in-workgroup hand-over.  A `volatile int*` made from an LDS
+// pointer is a GENERIC volatile access: the compiler emitted flat_load/flat_store with system scope (sc0 sc1) and
+// waited for vmcnt and lgkmcnt — every look at the published pivot number cost hundreds of cycles.
+__device__ __forceinline__ int lds_peek(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_poke(int* p, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+
 struct Published {   // what wave 0 hands to the rest of the workgroup (first 16 bytes of LDS)
     int v[4];        // [0] entering slot, [1] leaving position
 };
@@ -519,9 +531,37 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
     // block: the k-th row is a compile-time offset from one LDS address per array)
     const int wave = tid >> 6, lane = tid & 63;
     const int ut = tid - 64;
-    const int j = ut >= 0 ? ut % W : 0;
-    const int g = ut >= 0 ? ut / W : G;
-    const bool upd = ut >= 0 && g < G;
+    // Wave-aligned assignment when the non-basic columns fill whole waves (nn a multiple of 64, e.g. 128): every
+    // updating wave holds ONE row group and 64 consecutive columns, and the right-hand-side column's G owners sit
+    // together in a wave of their own.  With columns simply numbered through, the waves that contained the
+    // right-hand-side column (43 single-lane stores of xB per pivot) and a row-group boundary (two eta addresses per
+    // read, two branches of the pivot-row scaling) took 3.6-4.3 k cycles for an update the others did in 2.0-2.3 k,
+    // and the whole workgroup waited for them at the loop's barrier.
+    const int CW = nn / 64;
+    const bool aligned = (nn % 64) == 0 && G * CW + 1 <= (NT - 64) / 64 && m <= 256;
+    int j, g;
+    bool upd;
+    if (aligned) {
+        const int uw = wave - 1;
+        if (uw >= 0 && uw < G * CW) {
+            g = uw / CW;
+            j = (uw % CW) * 64 + lane;
+            upd = true;
+        } else {   // (wave 0 scans; the wave behind the column waves owns the right-hand side, see xbw below)
+            g = G;
+            j = nn;
+            upd = false;
+        }
+    } else {
+        j = ut >= 0 ? ut % W : 0;
+        g = ut >= 0 ? ut / W : G;
+        upd = ut >= 0 && g < G;
+    }
+    // The right-hand-side column (xB) in aligned mode: ONE wave, rows lane*RX .. lane*RX + RX-1 per lane (RX =
+    // ceil(m/64) <= 4) — its update is RX fmas per lane and ONE store per row pair, where three lanes with 43 rows each
+    // (the column-thread layout) needed 43 single-lane stores and were the slowest wave of every pivot.
+    const bool xbw = aligned && wave - 1 == G * CW;   // (a role of its own below: its state must not be live in the column waves' loop)
+    const int RX = (m + 63) / 64;
     double t[RPT];
     {
         double* stage = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(posofvar + n) + 15) & ~(uintptr_t)15);
@@ -609,9 +649,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             // the entering slot, then the pivot number it belongs to: the updating waves wait for the
             // number (LDS writes of one wave land in order) and hand the slot's column over before the
             // next barrier
-            volatile int* vp = pub;
-            vp[0] = se0;
-            vp[2] = iters + (priced_before_loop ? 0 : 1);
+            lds_poke(pub, se0);
+            lds_poke(pub + 2, iters + (priced_before_loop ? 0 : 1));
         }
     };
     // The pivot loop exists twice, once per ROLE, with the same sequence of workgroup barriers (a barrier
@@ -720,14 +759,60 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             BR_STAMP(6);
             ++iters;
         }
+    } else if (xbw) {
+        // ---- the right-hand-side column (xB) in aligned mode: ONE wave, rows lane*RX .. lane*RX + RX-1 per lane (RX =
+        // ceil(m/64) <= 4) — its update is RX fmas per lane and one store per row, where three lanes with 43 rows each
+        // (the column-thread layout) needed 43 single-lane stores and were the slowest wave of every pivot.  Same
+        // barrier sequence as the other two roles; same operations per element as a column thread's (:198-204).
+        double tx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane * RX + q;
+            tx[q] = (q < RX && i < m) ? b[i] : 0.0;
+        }
+        while (true) {
+            __syncthreads();   // (1)
+            BR_STAMP(7);
+            if (iters >= d.max_iter) {
+                status = LP_ITER_LIMIT;
+                break;
+            }
+            if (pub[0] < 0) {
+                status = LP_OPTIMAL;
+                break;
+            }
+            __syncthreads();   // (3)
+            const int r = pub[1];
+            if (r < 0) {
+                status = LP_UNBOUNDED;
+                break;
+            }
+            // (this wave's threads hold no share of the eta column: tid >= m)
+            if (lane == r / RX) {
+                const int qr = r - lane * RX;
+                prow[nn] = qr == 0 ? tx[0] : qr == 1 ? tx[1] : qr == 2 ? tx[2] : tx[3];
+            }
+            __syncthreads();   // (4)
+            const double pj = prow[nn];
+            const double sc = pj * lcol[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane * RX + q;
+                if (q < RX && i < m) {
+                    tx[q] = (i == r) ? sc : fma(lcol[i], pj, tx[q]);
+                    xcol[i] = tx[q];
+                }
+            }
+            BR_STAMP(6);
+            ++iters;
+        }
     } else {
         // ---- the entering column leaves its owners' registers (:176) as soon as wave 0 has priced the
         // pivot — no phase and no barrier of its own: the updating waves wait for the pivot number
         // behind their rank-1 update (wave 0 prices meanwhile) and the owners store before barrier (1)
         auto hand_over = [&]() {
-            volatile int* vp = pub;
-            while (vp[2] != iters) __builtin_amdgcn_s_sleep(1);
-            const int se_next = vp[0];
+            while (lds_peek(pub + 2) != iters) __builtin_amdgcn_s_sleep(1);
+            const int se_next = lds_peek(pub);
             if (upd && se_next >= 0 && j == se_next) {
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
@@ -747,7 +832,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
                 break;
             }
             BR_STAMP(0);
-            BR_STAMP(1);
             BR_STAMP(2);       // (wave 0 runs the ratio test)
             __syncthreads();   // (3)
             BR_STAMP(3);
@@ -805,6 +889,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             BR_STAMP(6);
             ++iters;
             hand_over();
+            BR_STAMP(1);   // (diagnostic builds: the hand-over's share of the wait in front of barrier (1))
         }
     }
     __syncthreads();
@@ -820,6 +905,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
         d.iters[lp] = iters;
         d.status[lp] = status;
     }
+    if (STAMPS && d.stamps && lp == 0 && (tid & 63) == 0) {   // every wave: its phase 6 and its wait at barrier (1)
+        d.stamps[32 + 2 * (tid >> 6)] = acc[6];
+        d.stamps[33 + 2 * (tid >> 6)] = acc[7];
+        d.stamps[48 + (tid >> 6)] = acc[1];   // (column waves: the entering column's hand-over)
+    }
     if (STAMPS && d.stamps && lp == 0 && (tid == 0 || tid == 64)) {
         for (int q = 0; q < 8; ++q) d.stamps[(tid ? 16 : 0) + q] = acc[q];
         d.stamps[(tid ? 16 : 0) + 8] = (unsigned long long)iters;
@@ -834,6 +924,10 @@ static int batched_reg_launch(lp_context* ctx, const BatchedDev& d) {
     size_t shm = dbl * 8 + sizeof(int) * (size_t)(nn + d.m + d.n);
     shm = (shm + 15) & ~(size_t)15;
     shm += 16 + sizeof(double) * (size_t)batched_stage_cols(d.m) * (size_t)batched_stage_stride(d.m);   // staging of the initial tableau
+    if (const char* e = getenv("LP_BATCHED_MIN_LDS_KB")) {   // experiments: fewer LPs per CU (84: one, 54: two, 40: three)
+        const size_t want = (size_t)atoi(e) * 1024;
+        if (shm < want) shm = want;
+    }
     LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG, STAMPS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG, STAMPS>), d.batch, NT, shm, ctx->stream, d);

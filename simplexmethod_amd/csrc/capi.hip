@@ -1321,8 +1321,8 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
         p->dev.eps = eps;
         p->dev.max_iter = max_iter;
         if (const char* sv = getenv("LP_BATCHED_STAMPS"); sv && !p->dev.stamps) {   // diagnostic build of the kernel (scripts/stamp_batched.py)
-            LP_HIP(ctx, hipMalloc(&p->dev.stamps, sizeof(unsigned long long) * 32));
-            LP_HIP(ctx, hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 32));
+            LP_HIP(ctx, hipMalloc(&p->dev.stamps, sizeof(unsigned long long) * 64));   // 32 phase sums + 2 per wave (16 waves)
+            LP_HIP(ctx, hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 64));
             p->dev.stamps_reg = std::strcmp(sv, "reg") == 0;
         }
         LP_HIP(ctx, hipEventRecord(p->ev0, ctx->stream));
@@ -1335,9 +1335,15 @@ int lp_batched_run(lp_batched_problem* p, double eps, int max_iter, float* ms_ou
         LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
         if (ms_out) *ms_out = ms;
         if (p->dev.stamps) {
-            unsigned long long h[32];
+            unsigned long long h[64];
             LP_HIP(ctx, hipMemcpy(h, p->dev.stamps, sizeof(h), hipMemcpyDeviceToHost));
             if (p->dev.stamps_reg) {
+                fprintf(stderr, "[batched stamps, register form] per wave: pricing | update phase, then the wait at the loop's barrier (incl. the entering column's hand-over):");
+                for (int w = 0; w < 8; ++w)
+                    fprintf(stderr, "  w%d %.0f+%.0f", w, (double)h[32 + 2 * w] / (double)(h[8] ? h[8] : 1), (double)h[33 + 2 * w] / (double)(h[8] ? h[8] : 1));
+                fprintf(stderr, "\n[batched stamps, register form] hand-over per wave:");
+                for (int w = 0; w < 8; ++w) fprintf(stderr, "  w%d %.0f", w, (double)h[48 + w] / (double)(h[8] ? h[8] : 1));
+                fprintf(stderr, "\n");
                 const char* names[8] = {"entering column -> LDS", "barrier", "ratio test | (idle)", "barrier",
                                         "eta column + pivot row -> LDS", "barrier",
                                         "reduced costs + pricing | rank-1 update", "barrier"};
