@@ -814,8 +814,19 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             while (lds_peek(pub + 2) != iters) __builtin_amdgcn_s_sleep(1);
             const int se_next = lds_peek(pub);
             if (upd && se_next >= 0 && j == se_next) {
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) ucol[g * RPT + k] = t[k];
+                // one lane per row group stores its RPT rows: this is the serial tail of every pivot (the ratio test
+                // waits for it), so exactly one ds_write_b64 with an immediate offset per row — the compiler's form
+                // copied every pair of rows into temporaries first (4 moves + 1 ds_write2_b64 per pair; a hand-written
+                // ds_write2_b64 per pair measured no faster than single stores)
+                const unsigned ua = (unsigned)(size_t)(ucol + g * RPT);
+#define BR_ST(K) if ((K) < RPT) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ua), "v"(t[(K) < RPT ? (K) : 0]), "n"((K) * 8) : "memory");
+                BR_ST(0) BR_ST(1) BR_ST(2) BR_ST(3) BR_ST(4) BR_ST(5) BR_ST(6) BR_ST(7) BR_ST(8) BR_ST(9) BR_ST(10)
+                BR_ST(11) BR_ST(12) BR_ST(13) BR_ST(14) BR_ST(15) BR_ST(16) BR_ST(17) BR_ST(18) BR_ST(19) BR_ST(20)
+                BR_ST(21) BR_ST(22) BR_ST(23) BR_ST(24) BR_ST(25) BR_ST(26) BR_ST(27) BR_ST(28) BR_ST(29) BR_ST(30)
+                BR_ST(31) BR_ST(32) BR_ST(33) BR_ST(34) BR_ST(35) BR_ST(36) BR_ST(37) BR_ST(38) BR_ST(39) BR_ST(40)
+                BR_ST(41) BR_ST(42) BR_ST(43)
+#undef BR_ST
+                static_assert(RPT <= 44, "extend the list above");
             }
         };
         hand_over();
