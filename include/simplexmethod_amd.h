@@ -257,6 +257,13 @@ int lp_enum_first_within(lp_enum_problem* p, uint64_t rank_begin, uint64_t rank_
 int lp_enum_vertex(lp_enum_problem* p, uint64_t rank, int n_orig, double* x_out, int* basis_out,
                    double* obj_out, int* verdict_out);
 void lp_enum_free(lp_enum_problem* p);
+/* 1 if the problem's leaf kernels divide plainly: a pass of the default kernels (fast reciprocal,
+ * the same bits for a pivot magnitude within [2^-500, 2^500]) met a pivot outside that range on a
+ * subset that was not singular anyway, and was repeated; later passes start there.  0 otherwise.  */
+int lp_enum_exact_division(const lp_enum_problem* p);
+/* Diagnostic (not part of the drop-in surface): the leaf kernels' fast reciprocal and the plain
+ * division 1.0 / x[i], both computed on the device, for the parity test of the two.              */
+int lp_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_out, double* plain_out);
 
 /* ---- Enumeration sharded over the GPUs of a node (README.md:27,40-42) ------
  * One participant per GPU — a process, or a host thread of one process — each with its own

@@ -81,6 +81,8 @@ SIGNATURES = {
     "lp_enum_first_within": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _u64p]),
     "lp_enum_vertex": (C.c_int, [_vp, C.c_uint64, C.c_int, _dp, _ip, _dp, _ip]),
     "lp_enum_free": (None, [_vp]),
+    "lp_enum_exact_division": (C.c_int, [_vp]),
+    "lp_debug_reciprocal": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "lp_comm_unique_id": (C.c_int, [_vp]),
     "lp_comm_create_rccl": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "lp_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -222,6 +224,13 @@ class Context:
         return rc
 
     # ---- simplex -------------------------------------------------------------------------
+    def debug_reciprocal(self, x):
+        """(fast, plain): the leaf kernels' fast reciprocal of x and 1.0 / x, both from the device."""
+        x = _f64(x).reshape(-1)
+        fast, plain = np.empty_like(x), np.empty_like(x)
+        self.check(self.lib.lp_debug_reciprocal(self.h, _d(x), len(x), _d(fast), _d(plain)))
+        return fast, plain
+
     def simplex_solve(self, A, b, c, basis, maximize=True, n_orig=None, eps=EPS,
                       max_iter=MAX_ITER):
         A = np.asarray(A, dtype=np.float64)
@@ -453,6 +462,11 @@ class EnumProblem:
             _i(bo) if want_vertex else None, C.byref(rank), C.byref(obj), counts))
         return dict(status=rc, x=x, basis=bo, rank=int(rank.value), obj=obj.value,
                     counts=[int(v) for v in counts])
+
+    @property
+    def exact_division(self):
+        """True once the leaf kernels divide plainly (include/simplexmethod_amd.h: lp_enum_exact_division)."""
+        return bool(self.ctx.lib.lp_enum_exact_division(self.h))
 
     def vertex(self, rank, n_orig=None):
         n_orig = self.n if n_orig is None else n_orig

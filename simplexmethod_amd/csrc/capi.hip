@@ -723,6 +723,14 @@ static void enum_destroy(lp_enum_problem* p) {
 
 // A freed problem keeps its allocations (all sized for the largest shape) in the context for the next
 // lp_enum_upload; beyond two kept shells it is really released.
+int lp_enum_exact_division(const lp_enum_problem* p) { return (p && p->exact_div) ? 1 : 0; }
+
+int lp_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_out, double* plain_out) {
+    if (!ctx || !x || !fast_out || !plain_out || n <= 0) return LP_BAD_ARG;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    return lp_enum_debug_reciprocal(ctx, x, n, fast_out, plain_out);
+}
+
 void lp_enum_free(lp_enum_problem* p) {
     if (!p) return;
     lp_context* ctx = p->ctx;
@@ -771,6 +779,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     } else {   // forget what the previous problem left behind
         p->list_valid = p->spec_valid = p->pchunks_valid = false;
         p->dense_active = p->dense_hint = false;
+        p->exact_div = false;
         p->pchunks.clear();
         p->shard_rank = p->shard_world = -1;
         p->last_begin = p->last_end = p->last_per_chunk = 0;

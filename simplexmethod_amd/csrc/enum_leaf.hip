@@ -71,10 +71,42 @@ struct LeafObj {
     double z;
 };
 
-template <int KD, int STRIDE, bool PERM, bool OBJ = false>
-__device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
-                                            unsigned used, double minp0, double maxp0, int m,
-                                            LeafObj* obj = nullptr) {
+// leaf_verdict<PERM>'s row order by (step 0's pivot row p0, step 1's q1): entry p0 * KD + q1 holds the byte
+// offsets (8 x row) of the KD-2 other rows, ascending, one per byte.  KD <= 6.
+template <int KD>
+__device__ __forceinline__ void leaf_row_table(unsigned* tab, int tid) {
+    static_assert(KD <= 6, "four rows per 32-bit entry");
+    if (tid < KD * KD) {
+        const int p0 = tid / KD, q1 = tid - p0 * KD;
+        unsigned pk = 0;
+        int k = 0;
+        for (int r = 0; r < KD; ++r)
+            if (r != p0 && r != q1 && k < KD - 2) pk |= (unsigned)(8 * r) << (8 * k++);
+        tab[tid] = pk;
+    }
+}
+
+// 1.0 / x for 2^-500 <= |x| <= 2^500: the instructions the compiler emits for an f64 division without its
+// range scaling (v_div_scale_f64 x 2) and special-case fix-up (v_div_fixup_f64), which leave an operand
+// in that range untouched (v_div_fmas_f64 is then a plain fma, and the numerator 1.0 makes the quotient
+// multiply an identity) — the same bits as `1.0 / x`, 7 instructions instead of 11
+// (tests/test_gpu_enum.py::test_leaf_reciprocal_matches_division).  Outside the range: garbage, no trap.
+__device__ __forceinline__ double recip_midrange(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double r1 = fma(r0, fma(-x, r0, 1.0), r0);
+    const double r2 = fma(r1, fma(-x, r1, 1.0), r1);
+    return fma(fma(-x, r2, 1.0), r2, r2);
+}
+constexpr double kRecipLo = 0x1p-500, kRecipHi = 0x1p500;
+
+// FAST: every division is recip_midrange(pivot); *redo is set if some pivot magnitude lay outside its range
+// (and the subset is not singular by a zero / NaN pivot anyway, which is decided before any quotient is
+// used) — the caller then repeats the subset with FAST = false (leaf_verdict below).
+template <int KD, int STRIDE, bool PERM, bool OBJ, bool FAST, bool TAB>
+__device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
+                                                 unsigned used, double minp0, double maxp0, int m,
+                                                 LeafObj* obj, bool* redo, const unsigned* rowtab) {
+    auto recip = [](double x) { return FAST ? recip_midrange(x) : 1.0 / x; };
     // column stride: a template constant, or (STRIDE == 0, list evaluation from 32-row records) obj->stride
     const int S = STRIDE > 0 ? STRIDE : obj->stride;
     // ---- phase 1: unused rows x chosen columns
@@ -89,7 +121,7 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     // The same for step 1: its pivot row is the first largest entry of column c[1] AFTER step 0's
     // elimination, among the rows other than p0 — five fmas on the two columns already read (the
     // same operations, operand for operand, that step 0 performs on the loaded matrix below).
-    double big0 = -1.0, bigs1 = -1.0;
+    double big0 = -1.0, bigs1 = -1.0, inv0 = 0.0;
     if constexpr (PERM) {
         double col0[KD], col1[KD];
         const double* cz = tab + c[0] * S;
@@ -104,43 +136,58 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         for (int r = 0; r < KD; ++r) big0 = fmax(big0, fabs(col0[r]));
 #pragma unroll
         for (int r = KD - 1; r >= 0; --r) p0 = (fabs(col0[r]) == big0) ? r : p0;   // descending: the first wins
-        double piv0 = col0[0], pr01 = col1[0];   // the pivot element and the pivot row's entry in column c[1]
-#pragma unroll
-        for (int r = 1; r < KD; ++r) {
-            piv0 = (r == p0) ? col0[r] : piv0;
-            pr01 = (r == p0) ? col1[r] : pr01;
-        }
-        const double inv0 = 1.0 / piv0;
+        // the pivot element and the pivot row's entry in column c[1]: read again at the chosen row (two LDS
+        // reads instead of 4 x (KD-1) selects)
+        const double piv0 = cz[p0], pr01 = cy[p0];
+        inv0 = recip(piv0);
         double a1[KD];
 #pragma unroll
         for (int r = 0; r < KD; ++r) {
             const double u = fma(-(col0[r] * inv0), pr01, col1[r]);
-            a1[r] = (r == p0) ? -1.0 : fabs(u);
+            // |u|, or for row p0 some value in (-2, -1] (the high word of -1.0 over u's low word: one select
+            // instead of two; all that matters is that it is negative, i.e. below every |u| and caught by the
+            // `bigs1 < 0` rule below if nothing else is a number)
+            a1[r] = __hiloint2double((r == p0) ? (int)0xBFF00000u : (__double2hiint(u) & 0x7FFFFFFF), __double2loint(u));
         }
+        // (v_max_f64 itself: the values are |arithmetic results| or the negative marker, never signalling NaNs,
+        // which the compiler cannot see behind the word-wise construction and would quiet one by one first)
 #pragma unroll
-        for (int r = 0; r < KD; ++r) bigs1 = fmax(bigs1, a1[r]);
+        for (int r = 0; r < KD; ++r) asm("v_max_f64 %0, %1, %2" : "=v"(bigs1) : "v"(bigs1), "v"(a1[r]));
         int q1 = 0;
 #pragma unroll
         for (int r = KD - 1; r >= 0; --r) q1 = (a1[r] == bigs1) ? r : q1;
         q1 = (bigs1 < 0.0) ? (p0 == 0 ? 1 : 0) : q1;   // (all NaN: any row other than p0; the subset is singular)
-        int row[KD];
-        row[0] = p0;
-        row[1] = q1;
-        const int lo = p0 < q1 ? p0 : q1, hi = p0 < q1 ? q1 : p0;
+        // byte offsets of the rows in their rotated order: p0, q1, then the others ascending — from the
+        // caller's table of all (p0, q1) pairs (leaf_row_table: one LDS read and a bit-field extract per row
+        // against ~8 integer instructions per row), or computed
+        unsigned off[KD];
+        off[0] = (unsigned)p0 * 8u;
+        off[1] = (unsigned)q1 * 8u;
+        if constexpr (TAB) {
+            static_assert(KD <= 6, "leaf_row_table");
+            const unsigned pk = rowtab[p0 * KD + q1];
 #pragma unroll
-        for (int k = 0; k < KD - 2; ++k) {
-            int idx = k + (k >= lo ? 1 : 0);
-            idx += (idx >= hi) ? 1 : 0;
-            row[k + 2] = idx;
+            for (int k = 0; k < KD - 2; ++k) off[k + 2] = (pk >> (8 * k)) & 0xFFu;
+        } else {
+            const int lo = p0 < q1 ? p0 : q1, hi = p0 < q1 ? q1 : p0;
+#pragma unroll
+            for (int k = 0; k < KD - 2; ++k) {
+                int idx = k + (k >= lo ? 1 : 0);
+                idx += (idx >= hi) ? 1 : 0;
+                off[k + 2] = (unsigned)idx * 8u;
+            }
         }
+        auto at = [](const double* col, unsigned o) {
+            return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(col) + o);
+        };
 #pragma unroll
         for (int t = 0; t < KD; ++t) {
             const double* col = tab + c[t] * S;
 #pragma unroll
-            for (int r = 0; r < KD; ++r) E[r][t] = col[row[r]];
+            for (int r = 0; r < KD; ++r) E[r][t] = at(col, off[r]);
         }
 #pragma unroll
-        for (int r = 0; r < KD; ++r) H[r] = tab[R * S + row[r]];
+        for (int r = 0; r < KD; ++r) H[r] = at(tab + R * S, off[r]);
     } else {
 #pragma unroll
         for (int t = 0; t < KD; ++t) {
@@ -194,7 +241,8 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
             }
             if (cc < KD) E[t][cc < KD ? cc : 0] = pr; else H[t] = pr;
         }
-        const double inv = 1.0 / E[t][t];   // the pivot element, now in its static position
+        // the pivot element, now in its static position (PERM, step 0: its reciprocal is already there)
+        const double inv = (PERM && t == 0) ? inv0 : recip(E[t][t]);
         INV[t] = inv;
 #pragma unroll
         for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
@@ -218,18 +266,19 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     const double pa = second ? a2 : a1, pb = second ? b2 : b1, ph = second ? h2 : h1;
     const double qa = second ? a1 : a2, qb = second ? b1 : b2, qh = second ? h1 : h2;
     const double big1 = fabs(pa);
-    const double inv1 = 1.0 / pa;
+    const double inv1 = recip(pa);
     const double l = -(qa * inv1);
     const double wqb = fma(l, pb, qb);
     const double rq = fma(l, ph, qh);
     const double big2 = fabs(wqb);
-    const double inv2 = 1.0 / wqb;
+    const double inv2 = recip(wqb);
     const double xb = rq * inv2;
     const double xa = fma(-pb, xb, ph) * inv1;
     if (!(big1 > 0.0) || !(big2 > 0.0)) sing = true;
     minp = fmin(minp, fmin(big1, big2));
     maxp = fmax(maxp, fmax(big1, big2));
     if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
+    if constexpr (FAST) *redo = !sing && !(minp >= kRecipLo && maxp <= kRecipHi);
     bool feas = (xa >= -1e-9) && (xb >= -1e-9);
     // the rows pivoted in phase 1: back-substitution
     double xr[OBJ ? KD - 2 : 1];
@@ -284,6 +333,24 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
         }
     }
     return sing ? 2 : (feas ? 0 : 1);
+}
+
+// FAST: the leaf kernels' hot form.  A subset whose pivots leave recip_midrange's range (and that is not
+// singular anyway) raises *viol; the kernel then sets EnumResult::range_flag, and the host repeats the pass
+// on the EXACT instantiations of the kernels (plain divisions; enum_prefix.hip: lp_enum_prefix_range).  Only
+// a problem scaled to ~1e-150 or ~1e150 as a whole gets there: a non-singular subset's pivots lie within
+// 1/(eps m) = 2^48 of each other.  (Repeating the one subset in place — the exact form inlined behind the
+// fast one, or called — cost the leaf loops 50-200 bytes of spills and the thin kernel a wave per SIMD.)
+template <int KD, int STRIDE, bool PERM, bool OBJ = false, bool FAST = false, bool TAB = false>
+__device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
+                                            unsigned used, double minp0, double maxp0, int m,
+                                            LeafObj* obj = nullptr, unsigned* viol = nullptr,
+                                            const unsigned* rowtab = nullptr) {
+    static_assert(!(OBJ && FAST), "the list evaluation divides plainly");
+    bool redo = false;
+    const int v = leaf_verdict_impl<KD, STRIDE, PERM, OBJ, FAST, TAB>(tab, c, R, U, used, minp0, maxp0, m, obj, &redo, rowtab);
+    if constexpr (FAST) *viol |= redo ? 1u : 0u;
+    return v;
 }
 
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
@@ -491,7 +558,7 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
 //         register allocation of MODE 1's loop is not disturbed (the two loops in one kernel cost
 //         that loop 12 %).
 // MODE 0 (m = 6): the root record is the depth m-6 node.
-template <int MODE>
+template <int MODE, bool EXACT>
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, unsigned long long begin,
                    unsigned long long end) {
@@ -506,6 +573,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
     __shared__ unsigned long long s_cnt[3];
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
+    __shared__ unsigned int s_rows[36];  // leaf_row_table of this kernel's lanes (5 columns each in MODE 2, else 6)
 
     const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
     const int4* const items = MODE == 2 ? pd.items2 : pd.items;   // built by k_enum_make_items
@@ -518,8 +586,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
     if (tid < 32) s_off[tid] = MODE == 2 ? pd.comb5[tid] : pd.comb6[tid];
+    leaf_row_table<(MODE == 2 ? 5 : 6)>(s_rows, tid);
     __syncthreads();
     unsigned int cntF = 0, cntI = 0, cntS = 0;
+    unsigned int viol = 0;   // !EXACT: a pivot left the fast reciprocal's range (leaf_verdict)
 
     // Software pipeline over work items: while item A is computed from LDS slice `buf`, the whole
     // record of item B (its index was drawn one iteration earlier) is in flight into registers,
@@ -711,7 +781,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 const unsigned pk = comb5[leaf];
 #pragma unroll
                 for (int t = 0; t < K5; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
-                const int verdict = leaf_verdict<K5, TS, true>(gtab, c, R2, U5, 0u, minp2, maxp2, m);
+                const int verdict = leaf_verdict<K5, TS, true, false, !EXACT, true>(gtab, c, R2, U5, 0u, minp2, maxp2, m, nullptr, &viol, s_rows);
                 if (verdict == 2) {
                     ++cntS;
                 } else if (verdict == 1) {
@@ -789,8 +859,9 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 const unsigned pk = (second ? comb1 : comb)[leaf];
 #pragma unroll
                 for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
-                const int verdict = leaf_verdict<KD, TS, true>(second ? tab1 : tab, c, second ? R1 : R, U, 0u,
-                                                               second ? minq : minp0, second ? maxq : maxp0, m);
+                const int verdict = leaf_verdict<KD, TS, true, false, !EXACT, true>(second ? tab1 : tab, c, second ? R1 : R, U, 0u,
+                                                                              second ? minq : minp0, second ? maxq : maxp0, m,
+                                                                              nullptr, &viol, s_rows);
                 if (verdict == 2) {
                     ++cntS;
                 } else if (verdict == 1) {
@@ -813,7 +884,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             const unsigned pk = comb[leaf];
 #pragma unroll
             for (int t = 0; t < KD; ++t) c[t] = (int)((pk >> (5 * t)) & 31u);
-            const int verdict = leaf_verdict<KD, TS, true>(tab, c, R, U, umask, minp0, maxp0, m);
+            const int verdict = leaf_verdict<KD, TS, true, false, !EXACT, true>(tab, c, R, U, umask, minp0, maxp0, m, nullptr, &viol, s_rows);
             if (verdict == 2) {
                 ++cntS;
             } else if (verdict == 1) {
@@ -832,6 +903,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
     if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
     if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
+    if (!EXACT && viol) atomicOr(&d.result->range_flag, 1ULL);
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
 }
@@ -839,6 +911,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
 // The tails: 8 lanes per depth m-7 record, lane j takes the j-th 7-subset (lexicographic) of the
 // record's last min(R, 8) selectable columns — C(8,7) = 8, C(7,7) = 1 — reading the record where
 // it lies in HBM (column stride PG).
+template <bool EXACT>
 __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev pd,
                                                              const double* __restrict__ roots,
                                                              int root_level, int root_cap,
@@ -855,6 +928,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     // counters leave a block with three atomics in total (one block per 32 records would put
     // 190 k atomics on three words for C(32,16): 0.7 ms at ~11 ns each)
     unsigned int cnt[3] = {0u, 0u, 0u};
+    unsigned int viol = 0;
     for (long long gid = (long long)blockIdx.x * LEAF_THREADS + tid; gid < (long long)nrec * 8;
          gid += (long long)gridDim.x * LEAF_THREADS) {
     const int rec = (int)(gid >> 3), j = (int)(gid & 7);
@@ -884,7 +958,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
                     free_rows &= free_rows - 1u;
                 }
                 const double* tab = Q + (size_t)(last + 1 - D) * PG;   // column q = column last+1+q
-                verdict = leaf_verdict<KD, PG, false>(tab, c, R, U, umask, pm->minp, pm->maxp, m);
+                verdict = leaf_verdict<KD, PG, false, false, !EXACT>(tab, c, R, U, umask, pm->minp, pm->maxp, m, nullptr, &viol);
             }
         }
     }
@@ -907,6 +981,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
         if ((tid & 63) == 0 && c) atomicAdd(&s_cnt[v], (unsigned long long)c);
     }
+    if (!EXACT && viol) atomicOr(&d.result->range_flag, 1ULL);
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
 }
@@ -961,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_enum_generic_items(EnumDev d, PrefixDev
 // DENSE (a degenerate LP: a large part of the range is feasible): no list — every subset is finished
 // without the early exit, its objective summed as the direct solver sums it, and its score (-inf if
 // not feasible) written to dense_scores[rank - begin]; the tie rule then runs over that array.
-template <int PGT, bool DENSE>
+template <int PGT, bool DENSE, bool EXACT>
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_enum_generic_leaves(EnumDev d, PrefixDev pd,
                                                                        const double* __restrict__ roots,
                                                                        unsigned long long range_subsets,
@@ -991,6 +1066,7 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
     if (tid == 0) s_best = lp_f64_key(-INFINITY);
     __syncthreads();
     const int nitems = min(pd.item_count[0], pd.item_cap);
+    unsigned int viol = 0;
     unsigned int cnt[3] = {0u, 0u, 0u};
     double* tab = s_rec[wave];
     int staged = -1;   // record in this wave's slice
@@ -1084,7 +1160,7 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
                     pd.dense_scores[rb + mine + k - begin] = score;
                     best = fmax(best, score);
                 } else {
-                    verdict = leaf_verdict<KD, TSG, true>(tab, c, R, U, 0u, minp0, maxp0, m);
+                    verdict = leaf_verdict<KD, TSG, true, false, !EXACT>(tab, c, R, U, 0u, minp0, maxp0, m, nullptr, &viol);
                     if (verdict == 0) {
                         const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
                         if (at < pd.list_cap) {
@@ -1119,6 +1195,7 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
         if (lane == 0 && x) atomicAdd(&s_cnt[v], (unsigned long long)x);
     }
     if (DENSE && best > -INFINITY) atomicMax(&s_best, lp_f64_key(best));
+    if (!DENSE && !EXACT && viol) atomicOr(&d.result->range_flag, 1ULL);
     __syncthreads();
     if (tid < 3 && s_cnt[tid]) atomicAdd(&d.result->counts[tid], s_cnt[tid]);
     if (DENSE && tid == 0 && s_best != lp_f64_key(-INFINITY)) atomicMax(&d.result->best_key, s_best);
@@ -1232,6 +1309,7 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         cap = (int)std::min<uint64_t>(got / sizeof(int4), 0x7FFFFFFFULL);
         return LP_OPTIMAL;
     };
+    const bool exact = p->exact_div;   // plain divisions (a pass of the fast kernels reported pivots out of range)
     const bool general = shape != 1 || dense || (fused && getenv("LP_ENUM_GENERIC"));   // (env: A/B on a tuned shape)
     if (general) {
         // one item per started run of kGenChunk subsets of a record
@@ -1244,11 +1322,14 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         hipLaunchKernelGGL(k_enum_generic_items<PGT>, grid_items, 256, 0, ctx->stream, p->dev, pd, roots, level, bound, \
                            b, e);                                                                                        \
         if (dense)                                                                                                       \
-            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, true>), grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd,      \
-                               roots, e - b, b);                                                                         \
+            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, true, true>), grid, LEAF_THREADS, 0, ctx->stream, p->dev,    \
+                               pd, roots, e - b, b);                                                                     \
+        else if (exact)                                                                                                  \
+            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, false, true>), grid, LEAF_THREADS, 0, ctx->stream, p->dev,   \
+                               pd, roots, e - b, b);                                                                     \
         else                                                                                                             \
-            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, false>), grid, LEAF_THREADS, 0, ctx->stream, p->dev, pd,     \
-                               roots, e - b, b);                                                                         \
+            hipLaunchKernelGGL((k_enum_generic_leaves<PGT, false, false>), grid, LEAF_THREADS, 0, ctx->stream, p->dev,  \
+                               pd, roots, e - b, b);                                                                     \
     } while (0)
         if (shape == 3) LP_GEN(32); else LP_GEN(PG);
 #undef LP_GEN
@@ -1286,16 +1367,24 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
             LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
         }
-        hipLaunchKernelGGL(k_enum_thin, (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12),
-                           LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+        const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12);
+        if (exact)
+            hipLaunchKernelGGL(k_enum_thin<true>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+        else
+            hipLaunchKernelGGL(k_enum_thin<false>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
         hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, s, p->dev, pd,
                            roots, level, bound, THIN_TAIL, lanes, b, e);
         if (side) {
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[1], s));          // both item tables are built
             LP_HIP(ctx, hipStreamWaitEvent(s1, ctx->aux_event[1], 0));
         }
-        hipLaunchKernelGGL(k_enum_leaves<2>, grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<1>, grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+        if (exact) {
+            hipLaunchKernelGGL((k_enum_leaves<2, true>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<1, true>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+        } else {
+            hipLaunchKernelGGL((k_enum_leaves<2, false>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<1, false>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+        }
         if (side) {
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[2], s1));
@@ -1305,7 +1394,43 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 1024), 1024, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, 1, b, e);
-        hipLaunchKernelGGL(k_enum_leaves<0>, grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        if (exact)
+            hipLaunchKernelGGL((k_enum_leaves<0, true>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
+        else
+            hipLaunchKernelGGL((k_enum_leaves<0, false>), grid6, LEAF_THREADS, 0, ctx->stream, p->dev, pd, roots, b, e);
     }
+    return LP_OPTIMAL;
+}
+
+// ---- self-test of recip_midrange against the compiler's division (lp_debug_reciprocal) ----
+namespace {
+__global__ void k_debug_reciprocal(const double* __restrict__ x, int n, double* __restrict__ fast,
+                                   double* __restrict__ plain) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i];
+    fast[i] = recip_midrange(v);
+    asm volatile("" : "+v"(v));   // (two separate computations, whatever the optimiser thinks of them)
+    plain[i] = 1.0 / v;
+}
+}  // namespace
+
+int lp_enum_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_out, double* plain_out) {
+    double *dx = nullptr, *df = nullptr, *dp = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    LP_HIP(ctx, hipMalloc(&dx, bytes));
+    hipError_t e = hipMalloc(&df, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dp, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_reciprocal, (unsigned)lp_ceil_div(n, 256), 256, 0, ctx->stream, dx, n, df, dp);
+        e = hipMemcpyAsync(fast_out, df, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(plain_out, dp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dx);
+    (void)hipFree(df);
+    (void)hipFree(dp);
+    LP_HIP(ctx, e);
     return LP_OPTIMAL;
 }

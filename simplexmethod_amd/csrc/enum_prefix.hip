@@ -279,7 +279,7 @@ __global__ void k_enum_root(EnumDev d, PrefixDev pd, double* dst) {
         r.best_key = lp_f64_key(-INFINITY);
         r.counts[0] = r.counts[1] = r.counts[2] = 0ULL;
         r.first_rank = ~0ULL;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0ULL;
+        r.range_flag = r.pad[0] = r.pad[1] = 0ULL;
         *d.result = r;
         *pd.list_count = 0ULL;
         *pd.overflow = 0;
@@ -351,8 +351,32 @@ int lp_enum_prefix_shape(const lp_enum_problem* p) {
 }
 bool lp_enum_prefix_supported(const lp_enum_problem* p) { return lp_enum_prefix_shape(p) != 0; }
 
+static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                             uint64_t counts[3], lp_enum_stats* stats, bool dense);
+
+// The leaf kernels run with the fast reciprocal (enum_leaf.hip: recip_midrange) until a pass reports a
+// pivot outside its exponent range on a subset that is not singular anyway; that pass is repeated with
+// plain divisions, and so is every later pass of the problem.
 int lp_enum_prefix_range(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
                          uint64_t counts[3], lp_enum_stats* stats, bool dense) {
+    if (const char* ev = getenv("LP_ENUM_EXACT_DIV")) p->exact_div = p->exact_div || atoi(ev) != 0;   // (A/B, tests)
+    p->h_result->range_flag = 0ULL;
+    int rc = prefix_range_once(p, begin, end, score_best, counts, stats, dense);
+    if (!p->exact_div && p->h_result->range_flag != 0ULL) {
+        p->exact_div = true;
+        lp_enum_stats first{};
+        if (stats) first = *stats;
+        rc = prefix_range_once(p, begin, end, score_best, counts, stats, dense);
+        if (stats) {
+            stats->kernel_ms += first.kernel_ms;
+            stats->launches += first.launches;
+        }
+    }
+    return rc;
+}
+
+static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, double* score_best,
+                             uint64_t counts[3], lp_enum_stats* stats, bool dense) {
     lp_context* ctx = p->ctx;
     const EnumDev& d = p->dev;
     hipStream_t s = ctx->stream;

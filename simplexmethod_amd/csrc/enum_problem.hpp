@@ -33,7 +33,8 @@ struct EnumResult {
     unsigned long long best_key;    // key of the best score (score = z if maximize else -z)
     unsigned long long counts[3];   // feasible, infeasible, singular
     unsigned long long first_rank;  // pass 2: smallest qualifying rank
-    unsigned long long pad[3];
+    unsigned long long range_flag;  // leaf kernels, fast reciprocal: some pivot left its range — the pass is repeated with plain divisions
+    unsigned long long pad[2];
 };
 
 struct EnumDev {
@@ -105,6 +106,9 @@ struct lp_enum_problem {
     // dense form of a pass (enum_prefix.hip): chosen when a pass finds more than a third of its range
     // feasible; dense_hint keeps later passes of this problem from listing first
     bool dense_active = false, dense_hint = false;
+    // the leaf kernels divide plainly (enum_leaf.hip: leaf_verdict): set for good once a pass of the fast
+    // kernels met pivots outside the fast reciprocal's exponent range, or by LP_ENUM_EXACT_DIV=1 (A/B, tests)
+    bool exact_div = false;
     // A range whose feasible subsets do not fit the list (degenerate LPs: up to every non-singular
     // basis is feasible) is enumerated in sub-ranges, one list at a time; pass 2 re-runs only the
     // sub-ranges whose best score can hold the winner.
@@ -149,6 +153,8 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
 // enum_prefix.hip
 bool lp_enum_prefix_supported(const lp_enum_problem* p);
 int lp_enum_prefix_shape(const lp_enum_problem* p);
+// enum_leaf.hip: recip_midrange(x[i]) and 1.0 / x[i] computed on the device (lp_debug_reciprocal)
+int lp_enum_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_out, double* plain_out);
 // LP_ITER_LIMIT = "could not run here (memory / a level buffer too small), use the direct path";
 // kEnumListOverflow = the feasible list was too small: *h_list_count holds the number of feasible
 // subsets of the range, the caller splits the range (capi.hip: enum_prefix_chunked)

@@ -724,3 +724,65 @@ def test_fuzz_small_structured_problems(ctx):
             if ref[0] == 0:
                 assert p.first_within(0, total, ref[1]) == o.enum_first_within(A, b, c, maximize, 0, total, ref[1])
         p.free()
+
+
+# ---- the leaf kernels' fast reciprocal (enum_leaf.hip: recip_midrange) and its way out
+
+def test_leaf_reciprocal_matches_division(ctx):
+    """recip_midrange(x) == 1.0 / x bit for bit on its whole range [2^-500, 2^500] (both computed on
+    the device): random mantissas over every exponent, the mantissas whose quotients sit next to a
+    rounding boundary, and both ends of the range."""
+    rng = np.random.default_rng(2026)
+    n = 1 << 21
+    mant = rng.integers(0, 1 << 52, size=n, dtype=np.uint64)
+    edge = np.array([0, 1, 2, 3, (1 << 52) - 1, (1 << 52) - 2, 1 << 51, (1 << 51) + 1, (1 << 51) - 1,
+                     0x5555555555555, 0xAAAAAAAAAAAAA, 0x6A09E667F3BCD, 0x6A09E667F3BCC], dtype=np.uint64)
+    mant[: 64 * len(edge)] = np.tile(edge, 64)
+    expo = rng.integers(-500, 500, size=n).astype(np.int64)
+    expo[:1001] = np.arange(-500, 501)
+    mant[:1001:7] = 0
+    x = ((expo + 1023).astype(np.uint64) << np.uint64(52) | mant).view(np.float64)
+    x[expo == 500] = 2.0 ** 500                      # (the range is closed: 2^500 itself, not beyond)
+    x[1::2] *= -1.0
+    assert np.all(np.abs(x) >= 2.0 ** -500) and np.all(np.abs(x) <= 2.0 ** 500)
+    fast, plain = ctx.debug_reciprocal(x)
+    assert np.array_equal(plain, 1.0 / x)            # the device's division is IEEE's
+    bad = np.flatnonzero(fast.view(np.uint64) != plain.view(np.uint64))
+    assert bad.size == 0, (x[bad[:4]], fast[bad[:4]], plain[bad[:4]])
+
+
+@pytest.mark.parametrize("m,n,seed", [(8, 18, 3), (7, 15, 4), (6, 13, 5), (17, 22, 6)])
+@pytest.mark.parametrize("scale", [2.0 ** -510, 2.0 ** 505])
+def test_prefix_pivots_outside_fast_reciprocal_range(ctx, m, n, seed, scale):
+    """A problem scaled so that every pivot lies outside the fast reciprocal's range: the pass reports
+    it, is repeated with plain divisions (visible through lp_enum_exact_division) and matches the oracle."""
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    A, b = A * scale, b * scale
+    total = o.binom(n, m)
+    st, z, counts = o.enum_range(A, b, c, True, 0, total)
+    assert counts[0] > 0
+    p = ctx.enum_problem(A, b, c, True)
+    assert not p.exact_division
+    assert p.range(0, total, capi.ENUM_PREFIX)[:3] == (st, z, counts)
+    assert p.exact_division
+    assert p.range(total // 3, total, capi.ENUM_PREFIX)[:3] == o.enum_range(A, b, c, True, total // 3, total)
+    assert p.range(0, total, capi.ENUM_DIRECT)[:3] == (st, z, counts)
+    p.free()
+
+
+@pytest.mark.parametrize("m,n,seed", [(8, 20, 11), (16, 22, 12), (7, 30, 13), (18, 24, 14), (6, 14, 15)])
+def test_prefix_fast_and_plain_division_agree(ctx, m, n, seed, monkeypatch):
+    """The default leaf kernels (fast reciprocal) and their plain-division instantiations
+    (LP_ENUM_EXACT_DIV=1) return the same bits; the default ones do not switch on ordinary data."""
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    p = ctx.enum_problem(A, b, c, True)
+    ref = p.range(0, total, capi.ENUM_PREFIX)[:3]
+    k = p.first_within(0, total, ref[1])
+    assert not p.exact_division
+    p.free()
+    monkeypatch.setenv("LP_ENUM_EXACT_DIV", "1")
+    q = ctx.enum_problem(A, b, c, True)
+    assert q.range(0, total, capi.ENUM_PREFIX)[:3] == ref and q.exact_division
+    assert q.first_within(0, total, ref[1]) == k
+    q.free()
