@@ -229,6 +229,49 @@ def pivot_leg(ctx, args):
     return out, roofline, roofline_whole, roofline_rank1, rankj
 
 
+def large_shape_leg(ctx, args):
+    """A tableau beyond the chip-resident shapes (m > 960): 2048 x 4096, 67 MB, 300 pivots.  AUTO takes the
+    one-launch-per-pivot path (simplex_overlap.hip): the out-of-place rank-1 update of pivot k streams the
+    tableau while one more workgroup of the same launch selects pivot k+1.  Here the pivot really is the
+    HBM-bound rank-1 update SURVEY 8(d) prices: algorithmic bytes 16*m*(n+1) per pivot / time."""
+    from simplexmethod_amd import capi
+    m, n, piv = 2048, 4096, 300
+    A, b, c, basis = capi.gen_lp(0, m, n)
+    p = ctx.simplex_problem(A, b, c, basis, True, n - m)
+    bytes_per_pivot = 16.0 * m * (n + 1)
+    names = {capi.SIMPLEX_LAUNCH: "launch", capi.SIMPLEX_LOOKAHEAD: "lookahead", capi.SIMPLEX_RESIDENT: "resident",
+             capi.SIMPLEX_OVERLAP: "overlap"}
+
+    def run(algo):
+        best = None
+        for _ in range(3):
+            p.reset()
+            rc, st = p.run(algo=algo, max_iter=piv)
+            if best is None or st.solve_ms < best[0]:
+                best = (st.solve_ms, st.pivots, int(st.algo_used), int(st.launches))
+        return best
+    auto = run(capi.SIMPLEX_AUTO)
+    two = run(capi.SIMPLEX_LAUNCH)
+    p.reset()
+    upd_ms = min(p.bench_update(m // 3, n // 5, 50) for _ in range(3))
+    p.free()
+    us = 1e3 * auto[0] / max(auto[1], 1)
+    rate = bytes_per_pivot / us / 1e3
+    upd = bytes_per_pivot / (upd_ms * 1e3) / 1e3
+    return {
+        "workload": f"simplex m={m} n={n} seed 0, first {piv} pivots (tableau {8e-6 * (m + 1) * (n + 1):.0f} MB)",
+        "algo_used": names.get(auto[2], str(auto[2])), "pivots": int(auto[1]), "launches": auto[3],
+        "us_per_pivot": round(us, 3),
+        "roofline": {"what": "whole pivot (selection overlapped with the update), algorithmic bytes / time",
+                     "bound": "hbm", "achieved": round(rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(rate / HBM_PEAK_GBS, 4)},
+        "two_launches_per_pivot_us": round(1e3 * two[0] / max(two[1], 1), 3),
+        "rank1_update_kernel_alone": {"kernel": "k_simplex_update (in place)", "avg_launch_us": round(1e3 * upd_ms, 3),
+                                      "achieved": round(upd, 1), "unit": "GB/s", "frac": round(upd / HBM_PEAK_GBS, 4),
+                                      "timing": "HIP events around 50 back-to-back launches"},
+    }
+
+
 def batched_leg(ctx, args, rank, world, reduce_device):
     """BASELINE configs[4]: 4096 random LPs of m=128, n=256 (seeds 0..4095), one LP per workgroup,
     "1 -> 8 GPUs": the LPs are independent, so rank r uploads and solves the LPs
@@ -590,6 +633,8 @@ def main():
         line["roofline_rank1_update"] = roofline_rank1
         if rankj is not None:
             line["rankj_update"] = rankj
+        if world == 1 and (args.pivot_m, args.pivot_n) == (512, 1024):
+            line["pivot_beyond_resident"] = large_shape_leg(ctx, args)
     if rank == 0 and world == 1 and not args.no_batched:
         line["enum"]["other_inputs"] = enum_inputs_leg(ctx, args)
         line["enum"]["wide_shapes"] = enum_wide_leg(ctx)

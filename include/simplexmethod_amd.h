@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 2 /* 2: lp_simplex_stats grew algo_used / fell_back; lp_enum_shard_abstain, lp_batched_shard_bounds */
+#define LP_ABI_VERSION 3 /* 2: lp_simplex_stats grew algo_used / fell_back; lp_enum_shard_abstain, lp_batched_shard_bounds; 3: LP_SIMPLEX_ALGO_OVERLAP, lp_enum_exact_division, lp_debug_reciprocal */
 
 /* Status codes; the C++ wrappers map them back to the
  * reference's exception types and messages.                                     */
@@ -97,6 +97,12 @@ enum {
                                       hand-off that times out (the workgroups never became
                                       co-resident) re-runs the solve on another algorithm:
                                       lp_simplex_stats::fell_back                          */
+    ,
+    LP_SIMPLEX_ALGO_OVERLAP = 4    /* one launch per pivot: the rank-1 update of pivot k streams the
+                                      tableau out of place while one more workgroup of the same launch
+                                      selects pivot k+1 from the old tableau and pivot k's eta; shapes
+                                      beyond the chip-resident ones (a second tableau buffer is
+                                      allocated on first use)                                */
 };
 
 typedef struct lp_simplex_stats {

@@ -14,7 +14,7 @@ from . import build as _build
 
 OPTIMAL, UNBOUNDED, ITER_LIMIT, SINGULAR, INFEASIBLE, BAD_ARG = range(6)
 SUBSET_FEASIBLE, SUBSET_INFEASIBLE, SUBSET_SINGULAR = range(3)
-SIMPLEX_AUTO, SIMPLEX_LAUNCH, SIMPLEX_LOOKAHEAD, SIMPLEX_RESIDENT = 0, 1, 2, 3
+SIMPLEX_AUTO, SIMPLEX_LAUNCH, SIMPLEX_LOOKAHEAD, SIMPLEX_RESIDENT, SIMPLEX_OVERLAP = 0, 1, 2, 3, 4
 ENUM_AUTO, ENUM_DIRECT, ENUM_PREFIX = 0, 1, 2
 U64_MAX = (1 << 64) - 1
 EPS = 1e-9        # Solver::EPS, SimplexSolover.h:13

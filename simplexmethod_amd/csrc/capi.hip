@@ -137,6 +137,8 @@ void lp_simplex_free(lp_simplex_problem* p) {
     (void)hipStreamSynchronize(ctx->stream);   // the arena goes back to the pool: nothing may still use it
     lp_pool_release(ctx, p->arena, p->arena_bytes);
     (void)hipFree(p->dscratchT);
+    (void)hipFree(p->ov_T);
+    (void)hipFree(p->ov_vec);
     (void)hipFree(p->look.stamps);
     (void)hipFree(p->res.stamps);
     if (p->h_state) {   // pinned block + events: kept for the next problem of this context
@@ -372,7 +374,8 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     }
     if (algo == LP_SIMPLEX_ALGO_AUTO)
         algo = p->res.G >= 1 ? LP_SIMPLEX_ALGO_RESIDENT
-                             : (p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD : LP_SIMPLEX_ALGO_LAUNCH);
+               : p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD
+               : lp_overlap_fits(p->dev.m) ? LP_SIMPLEX_ALGO_OVERLAP : LP_SIMPLEX_ALGO_LAUNCH;
     const int asked = algo;
     int rc;
     switch (algo) {
@@ -383,6 +386,9 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
             break;
         case LP_SIMPLEX_ALGO_LAUNCH:
             rc = lp_simplex_run_launch(p, eps, max_iter, stats_out);
+            break;
+        case LP_SIMPLEX_ALGO_OVERLAP:
+            rc = lp_simplex_run_overlap(p, eps, max_iter, stats_out);
             break;
         case LP_SIMPLEX_ALGO_LOOKAHEAD: {
             if (p->look.J < 1)

@@ -294,6 +294,84 @@ __device__ __forceinline__ int block_select_stage2(const double* vals, int len, 
     return wave_chain_select<WANT_MAX>(len, eps, best, load);
 }
 
+// ---------------------------------------------------------------------------
+// Workgroup-wide form of the chain scan over ANY number of entries (the one-workgroup selectors of
+// simplex_launch.hip / simplex_overlap.hip at large n, m: a lone wave walking 8192 reduced costs in tiles of
+// 1024 was 10-20 us of every pivot).  Every thread of the workgroup calls it.  produce(j) returns entry j with
+// ineligible entries as the sentinel; NaNs are replaced by the sentinel here (the chain never takes either).
+// STORE: the entries are also written to vals[j] (global or LDS scratch of >= len doubles); otherwise vals
+// already holds them.  Result as wave_chain_select's: the chain's last accepted index (or -1) and value.
+//   pass 1  thread t scans entries t, t + T, ...: its extreme and the first index holding it; waves and then the
+//           workgroup combine (M, jM = first index of the overall extreme).
+//   pass 2  "M beats every entry in front of jM by more than eps" — then the sequential chain must end on
+//           (M, jM) (wave_chain_select's fast path, one tile = everything) — else wave 0 replays the chain.
+// ---------------------------------------------------------------------------
+struct BlockChainScratch {   // LDS
+    double M[16];
+    int J[16];
+    int sel;
+    double best;
+};
+
+template <bool WANT_MAX, bool STORE, typename Produce>
+__device__ __forceinline__ int block_chain_select(int len, double eps, double& best, Produce produce, double* vals,
+                                                  BlockChainScratch* sc) {
+    const int tid = threadIdx.x, T = (int)blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const double sentinel = WANT_MAX ? -INFINITY : INFINITY;
+    double lv = sentinel;
+    int lj = INT_MAX;
+    for (int j = tid; j < len; j += T) {
+        double v = produce(j);
+        v = (v == v) ? v : sentinel;
+        if (STORE) vals[j] = v;
+        if (WANT_MAX ? (v > lv) : (v < lv)) {   // j ascends: the first index of the thread's extreme
+            lv = v;
+            lj = j;
+        }
+    }
+    const double Mw = wave_ext_f64<WANT_MAX>(lv);
+    const int jw = wave_min_i32((lv == Mw) ? lj : INT_MAX);
+    if (lane == 0) {
+        sc->M[wave] = Mw;
+        sc->J[wave] = jw;
+    }
+    __syncthreads();
+    double M = sentinel;
+    for (int w = 0; w < nwaves; ++w) M = WANT_MAX ? fmax(M, sc->M[w]) : fmin(M, sc->M[w]);
+    int jM = INT_MAX;
+    for (int w = 0; w < nwaves; ++w)
+        if (sc->M[w] == M && sc->J[w] < jM) jM = sc->J[w];
+    if (jM == INT_MAX) {   // nothing eligible
+        best = sentinel;
+        __syncthreads();   // (sc may be reused by the caller's next scan)
+        return -1;
+    }
+    int near = 0;
+    for (int j = tid; j < jM; j += T)
+        if (!beats<WANT_MAX>(M, vals[j], eps)) near = 1;
+    if (!__syncthreads_or(near)) {
+        best = M;
+        return jM;
+    }
+    if (wave == 0) {   // near-ties within eps in front of the extreme: the exact replay
+        double b;
+        auto load = [&](int j, bool& ok) {
+            ok = true;
+            return vals[j];
+        };
+        const int r = wave_chain_select<WANT_MAX>(len, eps, b, load);
+        if (lane == 0) {
+            sc->sel = r;
+            sc->best = b;
+        }
+    }
+    __syncthreads();
+    best = sc->best;
+    const int r = sc->sel;
+    __syncthreads();
+    return r;
+}
+
 template <bool WANT_MAX>
 __device__ __forceinline__ double ext2(double a, double b) {
     return WANT_MAX ? (a > b ? a : b) : (a < b ? a : b);

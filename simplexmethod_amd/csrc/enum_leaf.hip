@@ -43,7 +43,10 @@ namespace {
 
 constexpr int LEAF_THREADS = 256;
 constexpr int LEAF_WAVES = LEAF_THREADS / 64;
-constexpr int kGrandMin = 10;         // a depth m-5 node with >= 10 selectable columns (>= 252 subsets) is
+#ifndef LP_GRAND_MIN
+#define LP_GRAND_MIN 10
+#endif
+constexpr int kGrandMin = LP_GRAND_MIN;         // a depth m-5 node with >= 10 selectable columns (>= 252 subsets) is
                                       // finished by the two-level kernel (second in-LDS pivot, 5 columns per lane)
 constexpr int THIN_TAIL = 8;          // the thin kernel takes the subsets inside the last 8 columns
 constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
@@ -1367,7 +1370,9 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
             LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
         }
-        const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * 12);
+        int thin_per_cu = 12;
+        if (const char* ev = getenv("LP_ENUM_THIN_PER_CU")) thin_per_cu = std::max(1, atoi(ev));   // (A/B)
+        const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * thin_per_cu);
         if (exact)
             hipLaunchKernelGGL(k_enum_thin<true>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
         else

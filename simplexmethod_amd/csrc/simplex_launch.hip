@@ -514,6 +514,11 @@ int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_si
     const SimplexDev& d = p->dev;
     hipStream_t s = ctx->stream;
     const size_t shm = 2 * sizeof(double) * (size_t)(d.m + 2) + 16;
+    if (shm > 48 * 1024) {   // (m > 3070: opt in to more dynamic LDS than the default limit)
+        if (shm > 156 * 1024) LP_FAIL(ctx, LP_BAD_ARG, "simplex: m too large for the selector's LDS");
+        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_select),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    }
     int launches = 0;
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_state_init, 1, 1, 0, s, d, eps, max_iter);

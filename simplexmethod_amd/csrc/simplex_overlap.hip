@@ -1,0 +1,306 @@
+// simplex_overlap.hip — single LP beyond the chip-resident shapes: ONE launch per pivot, in which the
+// rank-1 update of pivot k streams the tableau (HBM-bound, every CU) while one more workgroup of the same
+// launch already selects pivot k+1.
+//
+// The two-launch form (simplex_launch.hip) is a chain  select -> update -> select -> ...: its update runs
+// at 5.9-6.9 TB/s on tableaus of 64-270 MB, but the one-workgroup selector between two updates (pricing
+// over n, a strided column gather, ratio test, pivot-row copy: 10-25 us) and the second kernel boundary
+// add 30-65 % to every pivot.  Nothing in the selection of pivot k+1 needs the UPDATED tableau as a whole:
+// it needs row m, column n, one column and one row of it, and each such entry is one fma away from the old
+// tableau — T_k[i][j] = fma(l_k[i], prow_k[j], T_{k-1}[i][j]) (pivot row: prow_k[j] * l_k[r]; entering
+// column: the unit vector), the very operations the update performs, so the bits are the same.
+// So the tableau is updated OUT OF PLACE between two buffers (T_{k-1} -> T_k), and launch k consists of
+//   workgroup 0        : selects pivot k+1 from T_{k-1} and pivot k's eta (l_k, prow_k, r_k, e_k): pricing
+//                        (SimplexSolover.h:152-174), unbounded test (:179), ratio test (:181-194), basis
+//                        bookkeeping (:196), eta column of F (:198-204) and the pivot row -> slot (k+1)&1;
+//   workgroups 1 ...   : T_k = update of T_{k-1} with pivot k's eta (slot k&1), 128 columns x 64 rows each.
+// Per pivot: max(update, select) + one kernel boundary instead of update + select + two boundaries.
+// Same pivots, same tableau bits as the other algorithms (tests/test_gpu_simplex.py).
+#include "device_select.hpp"
+#include "simplex_problem.hpp"
+
+namespace {
+
+constexpr int kRunning = -100;  // SimplexState::status while pivoting
+
+constexpr int OV_TX = 64;    // column pairs per workgroup (128 columns: 1 KiB per row segment)
+constexpr int OV_TY = 16;    // row groups per workgroup
+constexpr int OV_RPT = 4;    // rows per thread
+
+struct OverlapDev {
+    double* T[2];      // T[0] = SimplexDev::T; T_k lives in T[k & 1]
+    double* lcol[2];   // eta column of pivot k in lcol[k & 1] (entry r = 1/u_r, entry m = the cost row's multiplier)
+    double* prow[2];   // pivot row of pivot k before the update
+    int* slot;         // [2][4]: entering column, leaving position, valid, -
+};
+
+__global__ void k_overlap_init(SimplexDev d, OverlapDev ov, double eps, int max_iter) {
+    SimplexState* st = d.state;
+    st->status = kRunning;
+    st->iters = 0;
+    st->max_iter = max_iter;
+    st->enter = st->leave = -1;
+    st->pivot_valid = 0;
+    st->eps = eps;
+    for (int k = 0; k < 8; ++k) ov.slot[k] = 0;
+}
+
+// workgroup 0 of launch k: pivot k+1 from the tableau T_{k-1} (T_0 for k = 0) seen through pivot k's eta
+__device__ __forceinline__ void overlap_select(const SimplexDev& d, const OverlapDev& ov, int k, double* s_dyn) {
+    SimplexState* st = d.state;
+    const int m = d.m, n = d.n, ld = d.ld;
+    double* s_u = s_dyn;
+    double* s_ratio = s_dyn + (m + 2);
+    int* s_int = reinterpret_cast<int*>(s_dyn + 2 * (m + 2));
+    int& s_enter = s_int[0];
+    int& s_leave = s_int[1];
+    int& s_flag = s_int[2];
+    lpdev::BlockChainScratch* s_sc = reinterpret_cast<lpdev::BlockChainScratch*>(s_dyn + 2 * (m + 2) + 2);
+    const int tid = threadIdx.x;
+    const int cur = k & 1, nxt = cur ^ 1;
+    int* out = ov.slot + 4 * nxt;
+    if (st->status != kRunning) {
+        if (tid == 0) out[2] = 0;
+        return;
+    }
+    const double eps = st->eps;
+    if (st->iters >= st->max_iter) {  // while (iteration < MAX_ITER) ... throw, :429,:450
+        if (tid == 0) {
+            st->status = LP_ITER_LIMIT;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    const double* Ts = ov.T[k == 0 ? 0 : nxt];   // T_{k-1}
+    const int* in = ov.slot + 4 * cur;
+    const bool prev = k > 0 && in[2] != 0;       // pivot k is pending on T_{k-1} (applied by this launch's other workgroups)
+    const int ep = in[0], rp = in[1];
+    const double* lp = ov.lcol[cur];
+    const double* pp = ov.prow[cur];
+    // entry (i, j) of T_k: what the update writes there (simplex_launch.hip: k_simplex_update, operand for operand)
+    auto val = [&](int i, int j) {
+        double v = Ts[(size_t)i * ld + j];
+        if (prev) {
+            const double l = lp[i], pr = pp[j];
+            v = (i == rp) ? pr * l : fma(l, pr, v);
+            if (j == ep) v = (i == rp) ? 1.0 : 0.0;
+        }
+        return v;
+    };
+    // pricing: the updated cost row, staged in the (still unused) next pivot-row slot, every wave scanning
+    double* stage = ov.prow[nxt];
+    {
+        double best;
+        int e;
+        auto price = [&](int j) { return d.nonbasic[j] != 0 ? val(m, j) : (d.maximize ? -INFINITY : INFINITY); };   // complement(), :97-108
+        if (d.maximize)
+            e = lpdev::block_chain_select<true, true>(n, eps, best, price, stage, s_sc);
+        else
+            e = lpdev::block_chain_select<false, true>(n, eps, best, price, stage, s_sc);
+        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);  // :162 / :173
+        if (tid == 0) {
+            s_enter = optimal ? -1 : e;
+            s_flag = 0;
+        }
+    }
+    __syncthreads();
+    const int e = s_enter;
+    if (e < 0) {
+        if (tid == 0) {
+            st->status = LP_OPTIMAL;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    int any_pos = 0;
+    for (int i = tid; i <= m; i += blockDim.x) {   // u = Binv * A.col(enter), :176, incl. the reduced-cost row
+        const double ui = val(i, e);
+        s_u[i] = ui;
+        if (i < m) {
+            s_ratio[i] = (ui > eps) ? val(i, n) / ui : INFINITY;  // :185-186
+            if (!(ui <= eps)) any_pos = 1;  // (u.array() <= EPS).all(), :179
+        }
+    }
+    if (any_pos) s_flag = 1;
+    __syncthreads();
+    if (!s_flag) {
+        if (tid == 0) {
+            st->status = LP_UNBOUNDED;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    {
+        double theta;
+        auto ratio = [&](int i) { return s_ratio[i]; };   // ineligible rows hold +inf, which the < scan never takes
+        const int r = lpdev::block_chain_select<false, false>(m, eps, theta, ratio, s_ratio, s_sc);  // :187-190
+        if (tid == 0) s_leave = r;
+    }
+    __syncthreads();
+    const int r = s_leave;
+    if (r < 0) {  // :194
+        if (tid == 0) {
+            st->status = LP_UNBOUNDED;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    const double ur = s_u[r];
+    double* lout = ov.lcol[nxt];
+    double* pout = ov.prow[nxt];
+    for (int i = tid; i <= m; i += blockDim.x)  // F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204
+        lout[i] = (i == r) ? 1.0 / ur : -s_u[i] / ur;
+    for (int j = tid; j < ld; j += blockDim.x) pout[j] = val(r, j);
+    if (tid == 0) {
+        const int old = d.basis[r];
+        d.basis[r] = e;  // N(leave_pos) = enter, :196
+        d.nonbasic[e] = 0;
+        d.nonbasic[old] = 1;
+        const int it = st->iters;
+        if (it < d.trace_cap) {
+            d.trace_enter[it] = e;
+            d.trace_leave[it] = r;
+        }
+        st->iters = it + 1;
+        st->enter = e;
+        st->leave = r;
+        st->pivot_valid = 1;
+        out[0] = e;
+        out[1] = r;
+        out[2] = 1;
+    }
+}
+
+// Launch k.  nbx = column tiles of the update (its workgroups are 1 ... nbx * nby).
+__global__ __launch_bounds__(OV_TX* OV_TY) void k_simplex_overlap(SimplexDev d, OverlapDev ov, int k, int nbx, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    if (blockIdx.x == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        overlap_select(d, ov, k, s_dyn);
+        return;
+    }
+    if (k == 0 || dbg == 1) return;
+    const int cur = k & 1;
+    const int* sl = ov.slot + 4 * cur;
+    if (!sl[2]) return;
+    const int e = sl[0], r = sl[1];
+    const int b = (int)blockIdx.x - 1;
+    const int by = b / nbx, bx = b - by * nbx;
+    const int tx = threadIdx.x & (OV_TX - 1), ty = threadIdx.x / OV_TX;
+    const int ld2 = d.ld >> 1;
+    const int jp = bx * OV_TX + tx;  // column pair
+    if (jp >= ld2) return;
+    const int rows = d.m + 1;
+    const double2 pr = reinterpret_cast<const double2*>(ov.prow[cur])[jp];
+    const double2* S2 = reinterpret_cast<const double2*>(ov.T[cur ^ 1]);
+    double2* D2 = reinterpret_cast<double2*>(ov.T[cur]);
+    const double* lcol = ov.lcol[cur];
+    const int i0 = (by * OV_TY + ty) * OV_RPT;
+    const int je = e >> 1;
+    double2 t[OV_RPT];
+    double l[OV_RPT];
+#pragma unroll
+    for (int q = 0; q < OV_RPT; ++q) {
+        const int i = i0 + q;
+        if (i < rows) {
+            t[q] = S2[(size_t)i * ld2 + jp];
+            l[q] = lcol[i];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < OV_RPT; ++q) {
+        const int i = i0 + q;
+        if (i < rows) {
+            double2 v = t[q];
+            if (i == r) {
+                v.x = pr.x * l[q];
+                v.y = pr.y * l[q];
+            } else {
+                v.x = fma(l[q], pr.x, v.x);
+                v.y = fma(l[q], pr.y, v.y);
+            }
+            if (jp == je) {
+                const double unit = (i == r) ? 1.0 : 0.0;
+                if (e & 1) v.y = unit; else v.x = unit;
+            }
+            D2[(size_t)i * ld2 + jp] = v;
+        }
+    }
+}
+
+}  // namespace
+
+size_t lp_overlap_lds_bytes(int m) { return 2 * sizeof(double) * (size_t)(m + 2) + 16 + sizeof(lpdev::BlockChainScratch); }
+
+// The shape runs on this path if the selector's two m-vectors fit one CU's LDS.
+bool lp_overlap_fits(int m) { return lp_overlap_lds_bytes(m) <= 156 * 1024; }
+
+int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    hipStream_t s = ctx->stream;
+    if (!lp_overlap_fits(d.m)) LP_FAIL(ctx, LP_BAD_ARG, "overlapped simplex: m too large for the selector's LDS");
+    if (!p->ov_T) {   // second tableau, second eta slot: on first use
+        LP_HIP(ctx, hipMalloc(&p->ov_T, p->tableau_bytes));
+        LP_HIP(ctx, hipMalloc(&p->ov_vec, sizeof(double) * ((size_t)d.m + 2 + (size_t)d.ld) + 64));
+    }
+    OverlapDev ov;
+    ov.T[0] = d.T;
+    ov.T[1] = p->ov_T;
+    ov.lcol[0] = d.lcol;
+    ov.prow[0] = d.prow;
+    ov.prow[1] = p->ov_vec;                         // ld doubles (16-byte aligned: read as double2)
+    ov.lcol[1] = p->ov_vec + d.ld;                  // m + 2 doubles
+    ov.slot = reinterpret_cast<int*>(p->ov_vec + d.ld + d.m + 2);   // 8 ints
+    const size_t shm = lp_overlap_lds_bytes(d.m);
+    if (shm > 48 * 1024 && !p->ov_attr) {
+        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_overlap),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        p->ov_attr = true;
+    }
+    const int nbx = lp_ceil_div(d.ld / 2, OV_TX), nby = lp_ceil_div(d.m + 1, OV_TY * OV_RPT);
+    const unsigned grid = 1u + (unsigned)nbx * (unsigned)nby;
+    int launches = 0;
+    LP_HIP(ctx, hipEventRecord(p->ev0, s));
+    hipLaunchKernelGGL(k_overlap_init, 1, 1, 0, s, d, ov, eps, max_iter);
+    ++launches;
+    int batch = 16, k = 0;
+    int status = kRunning;
+    const int dbg = getenv("LP_OVERLAP_DEBUG") ? atoi(getenv("LP_OVERLAP_DEBUG")) : 0;   // 1: selection only (timing)
+    // Launches turn into no-ops once the state leaves kRunning, so they are queued in growing batches and
+    // the status word is polled once per batch.
+    for (;;) {
+        for (int q = 0; q < batch; ++q, ++k)
+            hipLaunchKernelGGL(k_simplex_overlap, grid, OV_TX * OV_TY, shm, s, d, ov, k, nbx, dbg);
+        launches += batch;
+        LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
+        LP_HIP(ctx, hipStreamSynchronize(s));
+        status = p->h_state->status;
+        if (status != kRunning) break;
+        if (batch < 256) batch *= 2;
+    }
+    // T_N lives in buffer N & 1 (launch N applied the last pivot; the launches behind it did nothing)
+    if (p->h_state->iters & 1) LP_HIP(ctx, hipMemcpyAsync(d.T, p->ov_T, p->tableau_bytes, hipMemcpyDeviceToDevice, s));
+    LP_HIP(ctx, hipEventRecord(p->ev1, s));
+    LP_HIP(ctx, hipEventSynchronize(p->ev1));
+    LP_HIP(ctx, hipGetLastError());
+    float ms = 0.f;
+    LP_HIP(ctx, hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_status = status;
+    p->last_algo = LP_SIMPLEX_ALGO_OVERLAP;
+    p->last_iters = p->h_state->iters;
+    if (stats) {
+        stats->status = status;
+        stats->pivots = p->h_state->iters;
+        stats->launches = launches;
+        stats->solve_ms = ms;
+        stats->update_ms = 0.f;
+        stats->update_launches = 0;
+        stats->bytes_per_pivot = 16.0 * (double)d.m * (double)(d.n + 1);
+    }
+    return status;
+}

@@ -75,6 +75,9 @@ struct lp_simplex_problem {
     double* dT0 = nullptr;        // pristine initial tableau (after crash) for lp_simplex_reset; also the
                                   // staging area of the upload (column-major A) and of the crash's row permutation
     double* dscratchT = nullptr;  // scratch copy used by the update micro-benchmarks (allocated on first use)
+    double* ov_T = nullptr;       // simplex_overlap.hip: the second tableau buffer, and the second eta slot
+    double* ov_vec = nullptr;     // (pivot row, eta column, 8 ints); both allocated on first use
+    bool ov_attr = false;         // the overlapped kernel's dynamic-LDS opt-in has been made
     int* dbasis0 = nullptr;
     unsigned char* dnonbasic0 = nullptr;
     double* dx = nullptr;         // n: extracted vertex
@@ -100,6 +103,10 @@ int lp_simplex_phase2_costs(lp_simplex_problem* p, const double* cost, int n_rea
 int lp_simplex_run_launch(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 int lp_simplex_extract_x(lp_simplex_problem* p, double* dx);
 int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, float* ms_out);
+
+// simplex_overlap.hip
+bool lp_overlap_fits(int m);
+int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 
 // simplex_resident.hip
 int lp_resident_plan(int m, int n, ResidentDev* out);   // fills G/stride/mpad/offsets; 0 if the shape does not fit

@@ -10,7 +10,7 @@ from tests import lpcases
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = [capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD, capi.SIMPLEX_RESIDENT]
+ALGOS = [capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD, capi.SIMPLEX_RESIDENT, capi.SIMPLEX_OVERLAP]
 
 
 def _run(ctx, A, b, c, basis, maximize, n_orig, trace_cap=1 << 14, max_iter=capi.MAX_ITER,
@@ -122,6 +122,21 @@ def test_resident_shape_limit(ctx):
     p.free()
     g = _run(ctx, A, b, c, basis, True, n - m, algo=capi.SIMPLEX_AUTO)
     assert g["algo_used"] == capi.SIMPLEX_LOOKAHEAD
+    _assert_bit_exact(g, r)
+
+
+@pytest.mark.parametrize("max_iter", [1, 2, 37, 38])
+def test_overlap_large_shape(ctx, max_iter):
+    """2048 x 4096 (beyond the chip-resident shapes, look-ahead depth 1): AUTO takes the one-launch-per-pivot
+    path whose update of pivot k overlaps the selection of pivot k+1 (simplex_overlap.hip).  Stopped after an
+    odd and an even number of pivots (the tableau alternates between two buffers): same pivots and the same
+    tableau, bit for bit, as the oracle."""
+    m, n = 2048, 4096
+    A, b, c, basis = lpcases.random_lp(47, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=64, want_tableau=True, max_iter=max_iter)
+    assert r["status"] == o.ITER_LIMIT and r["iters"] == max_iter
+    g = _run(ctx, A, b, c, basis, True, n - m, trace_cap=64, max_iter=max_iter, algo=capi.SIMPLEX_AUTO)
+    assert g["algo_used"] == capi.SIMPLEX_OVERLAP
     _assert_bit_exact(g, r)
 
 
