@@ -14,14 +14,14 @@ for _ in range(10):
     r = p.range(0, p.total)
     best = min(best, time.perf_counter() - t0)
 print("%s: full pass %.3f ms wall, kernel_ms %.3f, z=%r counts=%s" % (os.environ.get("LP_LIB_PATH", "default"), best * 1e3, r[3].kernel_ms if hasattr(r[3], "kernel_ms") else -1, r[1], r[2]), flush=True)
-cuts = [p.total * k // 8 for k in range(9)]
+from simplexmethod_amd import dist as lpdist
 worst = 0.0
-for lo, hi in zip(cuts[:-1], cuts[1:]):
+for lo, hi in [lpdist.balanced_shard_bounds(32, 16, r, 8) for r in range(8)]:
     p.range(lo, hi)
     bb = 1e9
-    for _ in range(5):
+    for _ in range(8):
         t0 = time.perf_counter()
         p.range(lo, hi)
         bb = min(bb, time.perf_counter() - t0)
     worst = max(worst, bb)
-print("   slowest of 8 equal-rank shards %.3f ms" % (worst * 1e3), flush=True)
+print("   slowest of the 8 cost-balanced shards %.3f ms" % (worst * 1e3), flush=True)

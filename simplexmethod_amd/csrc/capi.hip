@@ -705,23 +705,18 @@ static void enum_destroy(lp_enum_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->dA); (void)hipFree(p->db); (void)hipFree(p->dc); (void)hipFree(p->dbinom);
-    (void)hipFree(p->dev.result); (void)hipFree(p->dev.chunk_best);
+    (void)hipFree(p->d_pass); (void)hipFree(p->dev.chunk_best);
     (void)hipFree(p->dvx); (void)hipFree(p->dvi);
-    (void)hipFree(p->prefix.level_counts); (void)hipFree(p->prefix.overflow);
     (void)hipFree(p->prefix.root_cursor);
     enum_list_release(p);
     lp_pool_release(p->ctx, p->prefix.dense_scores, sizeof(double) * p->prefix.dense_cap);
-    (void)hipFree(p->prefix.list_count);
     lp_pool_release(p->ctx, p->prefix.items, sizeof(int4) * (size_t)p->prefix.item_cap);
     lp_pool_release(p->ctx, p->prefix.items2, sizeof(int4) * (size_t)p->prefix.item_cap2);
     (void)hipFree(p->prefix.item_count);
     if (p->h_item_count) (void)hipHostFree(p->h_item_count);
     lp_pool_release(p->ctx, p->prefix_buf[0], p->prefix_buf_bytes[0]);
     lp_pool_release(p->ctx, p->prefix_buf[1], p->prefix_buf_bytes[1]);
-    if (p->h_level_counts) (void)hipHostFree(p->h_level_counts);
-    if (p->h_list_count) (void)hipHostFree(p->h_list_count);
-    if (p->h_overflow) (void)hipHostFree(p->h_overflow);
-    if (p->h_result) (void)hipHostFree(p->h_result);
+    if (p->h_pass) (void)hipHostFree(p->h_pass);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -823,11 +818,17 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipMalloc(&p->db, sizeof(double) * (size_t)kEnumMaxM));
         LP_TRY(hipMalloc(&p->dc, sizeof(double) * (size_t)kEnumMaxN));
         LP_TRY(hipMalloc(&p->dbinom, sizeof(unsigned long long) * binom.size()));
-        LP_TRY(hipMalloc(&d.result, sizeof(EnumResult)));
+        LP_TRY(hipMalloc(&p->d_pass, sizeof(EnumPassBlock)));
+        d.result = &p->d_pass->result;
         LP_TRY(hipMalloc(&d.chunk_best, sizeof(double) * (size_t)(p->chunk_cap + 64)));
         LP_TRY(hipMalloc(&p->dvx, sizeof(double) * (kEnumMaxM + 1)));
         LP_TRY(hipMalloc(&p->dvi, sizeof(int) * (kEnumMaxM + 1)));
-        LP_TRY(hipHostMalloc(&p->h_result, sizeof(EnumResult)));
+        LP_TRY(hipHostMalloc(&p->h_pass, sizeof(EnumPassBlock)));
+        std::memset(p->h_pass, 0, sizeof(EnumPassBlock));
+        p->h_result = &p->h_pass->result;
+        p->h_list_count = &p->h_pass->list_count;
+        p->h_overflow = &p->h_pass->overflow;
+        p->h_level_counts = p->h_pass->level_counts;
         LP_TRY(hipEventCreate(&p->ev0));
         LP_TRY(hipEventCreate(&p->ev1));
         LP_TRY(hipMemcpyAsync(p->dbinom, binom.data(), sizeof(unsigned long long) * binom.size(),
@@ -838,16 +839,13 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
     LP_TRY(hipMemcpyAsync(p->dc, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     if (fresh) {   // shared-prefix path: small control words, the feasible list
         PrefixDev& pd = p->prefix;
-        LP_TRY(hipMalloc(&pd.level_counts, sizeof(int) * 32));
+        pd.level_counts = p->d_pass->level_counts;
         LP_TRY(hipMalloc(&pd.item_count, 2 * sizeof(int)));
         LP_TRY(hipHostMalloc(&p->h_item_count, sizeof(int)));
-        LP_TRY(hipMalloc(&pd.overflow, sizeof(int)));
+        pd.overflow = &p->d_pass->overflow;
         LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
         LP_TRY(enum_list_alloc(p, want_cap));
-        LP_TRY(hipMalloc(&pd.list_count, sizeof(unsigned long long)));
-        LP_TRY(hipHostMalloc(&p->h_level_counts, sizeof(int) * 32));
-        LP_TRY(hipHostMalloc(&p->h_list_count, sizeof(unsigned long long)));
-        LP_TRY(hipHostMalloc(&p->h_overflow, sizeof(int)));
+        pd.list_count = &p->d_pass->list_count;
         if (!ctx->dcomb6 || !ctx->dcomb5) {   // (shape-independent: once per context)
             // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
             std::vector<unsigned> comb6(32, 0u);

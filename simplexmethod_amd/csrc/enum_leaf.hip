@@ -315,6 +315,9 @@ __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&
     };
     if constexpr (OBJ) {
         double z = 0.0;
+        // (unrolled: the rows' loads of four prefix depths are in flight together — the list evaluation is one
+        // lane per entry and nothing but dependent round trips to the records in HBM)
+#pragma unroll 4
         for (int k = 0; k < obj->D; ++k) {
             int i = obj->prow[k];
             if constexpr (PERM) i = KD + __builtin_popcount(obj->used & ((1u << i) - 1u));
@@ -1354,7 +1357,7 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
     if (fused) {
         // The three leaf kernels are independent of each other (own item table / work cursor, results
         // through atomics), and the thin kernel does not even need the item tables: they run on three
-        // streams, so that the thin kernel overlaps the item builder and every kernel's tail (persistent
+        // streams, so that the thin kernel runs beside the leaf kernels and every kernel's tail (persistent
         // waves running out of items) is filled by the next kernel's blocks.  The library's stream
         // waits for the other two before anything that follows (list evaluation, result copy).
         if (!ctx->aux_stream[0]) {
@@ -1370,19 +1373,31 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
             LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
         }
-        int thin_per_cu = 12;
+        // The thin kernel is latency-bound (8 lanes per record, gathers from HBM: half of its VALU slots idle) and
+        // nothing waits for it: a small grid of it (2 workgroups per CU, grid-stride) is queued BEHIND the item
+        // builder, which is on the leaf kernels' critical path, and runs beside the leaf kernels.  (Launched first
+        // with 12 workgroups per CU it held the chip while the item builder ran: 14.72 -> 14.50 ms on the whole
+        // range, 2.26 -> 2.21 ms on the slowest 8-way shard; scripts/time_enum_variant.py.)
+        int thin_per_cu = 2;
         if (const char* ev = getenv("LP_ENUM_THIN_PER_CU")) thin_per_cu = std::max(1, atoi(ev));   // (A/B)
         const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * thin_per_cu);
-        if (exact)
-            hipLaunchKernelGGL(k_enum_thin<true>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
-        else
-            hipLaunchKernelGGL(k_enum_thin<false>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+        int thin_order = 1;   // 0: thin first (beside the item builder); 1: behind the item builder; 2: behind the leaf kernels
+        if (const char* ev = getenv("LP_ENUM_THIN_ORDER")) thin_order = atoi(ev);   // (A/B)
+        auto launch_thin = [&]() {
+            if (exact)
+                hipLaunchKernelGGL(k_enum_thin<true>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+            else
+                hipLaunchKernelGGL(k_enum_thin<false>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
+        };
+        if (thin_order == 0) launch_thin();
         hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, s, p->dev, pd,
                            roots, level, bound, THIN_TAIL, lanes, b, e);
         if (side) {
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[1], s));          // both item tables are built
             LP_HIP(ctx, hipStreamWaitEvent(s1, ctx->aux_event[1], 0));
+            if (thin_order >= 1) LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[1], 0));
         }
+        if (thin_order == 1) launch_thin();
         if (exact) {
             hipLaunchKernelGGL((k_enum_leaves<2, true>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, true>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
@@ -1390,6 +1405,7 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             hipLaunchKernelGGL((k_enum_leaves<2, false>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, false>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         }
+        if (thin_order >= 2) launch_thin();
         if (side) {
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));
             LP_HIP(ctx, hipEventRecord(ctx->aux_event[2], s1));

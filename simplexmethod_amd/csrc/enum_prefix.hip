@@ -520,7 +520,6 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
         if (rc) return rc;
     }
     ++launches;
-    LP_HIP(ctx, hipMemcpyAsync(p->h_level_counts, pd.level_counts, sizeof(int) * 32, hipMemcpyDeviceToHost, s));
     // objectives of the (few) feasible subsets by the direct solver, and the tie rule against this
     // range's own best score (what a sharded run asks next): queued behind the leaf kernels
     constexpr double kSpecTol = 1e-9;   // Solver::EPS, the tolerance dist.py / EnumerationSolver use
@@ -530,9 +529,8 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
     else
         lp_enum_queue_list_tail(p, kSpecTol, fused ? p->prefix_buf[cur] : nullptr);
     LP_HIP(ctx, hipEventRecord(p->ev1, s));
-    LP_HIP(ctx, hipMemcpyAsync(p->h_result, d.result, sizeof(EnumResult), hipMemcpyDeviceToHost, s));
-    LP_HIP(ctx, hipMemcpyAsync(p->h_list_count, pd.list_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    LP_HIP(ctx, hipMemcpyAsync(p->h_overflow, pd.overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    // result, list count, overflow flag and level counts: one block, one copy (enum_problem.hpp: EnumPassBlock)
+    LP_HIP(ctx, hipMemcpyAsync(p->h_pass, p->d_pass, sizeof(EnumPassBlock), hipMemcpyDeviceToHost, s));
     LP_HIP(ctx, hipStreamSynchronize(s));
     LP_HIP(ctx, hipGetLastError());
     for (int t = 1; t <= D0; ++t)

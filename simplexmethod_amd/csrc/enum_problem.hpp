@@ -37,6 +37,17 @@ struct EnumResult {
     unsigned long long pad[2];
 };
 
+// What the host reads back after a shared-prefix pass, in ONE device block and one pinned mirror (one copy per
+// pass instead of four: each small device-to-host copy is a 5-20 us blit on the stream, a tenth of the fixed cost
+// of an 8-way shard).  EnumDev::result, PrefixDev::list_count / overflow / level_counts point into the device block.
+struct EnumPassBlock {
+    EnumResult result;
+    unsigned long long list_count;
+    int overflow;
+    int pad;
+    int level_counts[32];
+};
+
 struct EnumDev {
     int m, n, lda;                  // lda = n + 1 (odd stride: conflict-free row gathers)
     int maximize;
@@ -81,7 +92,9 @@ struct lp_enum_problem {
     double* dc = nullptr;
     unsigned long long* dbinom = nullptr;
     std::vector<double> hA, hb, hc;  // host copies (column-major A) for argument checks only
-    EnumResult* h_result = nullptr;  // pinned
+    EnumPassBlock* d_pass = nullptr; // the device block behind dev.result, prefix.list_count / overflow / level_counts
+    EnumPassBlock* h_pass = nullptr; // pinned mirror; the four h_* pointers below point into it
+    EnumResult* h_result = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // chunking of the last lp_enum_range call (pass 2 narrows to the first qualifying chunk)
     uint64_t last_begin = 0, last_end = 0, last_per_chunk = 0;
