@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--pivot-n", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pivot", action="store_true")
+    ap.add_argument("--no-large-shape", action="store_true",
+                    help="skip the 2048x4096 leg (profiles: keeps k_simplex_update's per-launch average to the 512x1024 workload)")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--batch", type=int, default=4096)
     return ap.parse_args()
@@ -633,7 +635,7 @@ def main():
         line["roofline_rank1_update"] = roofline_rank1
         if rankj is not None:
             line["rankj_update"] = rankj
-        if world == 1 and (args.pivot_m, args.pivot_n) == (512, 1024):
+        if world == 1 and (args.pivot_m, args.pivot_n) == (512, 1024) and not args.no_large_shape:
             line["pivot_beyond_resident"] = large_shape_leg(ctx, args)
     if rank == 0 and world == 1 and not args.no_batched:
         line["enum"]["other_inputs"] = enum_inputs_leg(ctx, args)

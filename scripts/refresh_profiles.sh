@@ -13,7 +13,7 @@ mkdir -p "$O"
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" > "$O/bench_profiled.log" 2>&1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_pivot" -- python3 "$R/bench.py" --no-batched --no-cpu-baseline > "$O/bench_pivot_profiled.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_pivot" -- python3 "$R/bench.py" --no-batched --no-cpu-baseline --no-large-shape > "$O/bench_pivot_profiled.log" 2>&1
 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/scripts/pmc_traffic.py" > "$O/pmc_fetch.log" 2>&1
 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/scripts/pmc_traffic.py" > "$O/pmc_write.log" 2>&1
 timeout -k 10 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d "$O/pmc_enum" -- python3 "$R/scripts/pmc_enum.py" > "$O/pmc_enum.log" 2>&1
