@@ -186,6 +186,204 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// phase 1, wide levels of 16-row records (round 3): the PARENT RECORD STAGED IN LDS.
+// k_enum_expand above walks a parent's children in rounds of four and fetches every operand from the
+// record where it lies (HBM the first time, L2 afterwards): the pivot column, then the remaining
+// columns six at a time — ~4 dependent memory round trips per round, ~20 per parent, one parent after the
+// other in each wave.  PMC (scripts/pmc_kernel_bytes.py): the last level of C(32,16) moves 3.66 GB (1.14 GB
+// of parents read, 2.58 GB of children written — only the columns behind a node's last chosen one are
+// stored) in 1.7 ms = 2.2 TB/s: a latency chain, not a bandwidth limit.
+// Here a wave copies the meaningful part of its parent (columns > last_col and the rhs: contiguous, <= 4.2 KB)
+// into its private LDS slice with ONE coalesced load per lane-slot, issued one parent AHEAD (the registers
+// of parent i+1 and its metadata are in flight while parent i is expanded; which part to fetch is known
+// from the block's first phase, which reads every parent's last_col anyway).  Every operand of every child
+// — its pivot column, the pivot row's entries (a plain LDS read at the pivot row instead of a
+// ds_bpermute of the loaded column), its own entries — then comes from LDS, and the only global traffic
+// inside the loop is the children's stores.  Same arithmetic, operand for operand; same slots, same
+// metadata as k_enum_expand.  The per-level table of subset counts C(n-1-a, m-t-1) lives in LDS as well: read
+// out of L2 by every parent's lane in phase A and again per lane in the expansion, those dependent little loads
+// — not the records — were what a parent cost (staging the records alone changed nothing: 1.82 against 1.66 ms
+// for the last level; with the table in LDS 1.04 ms = 3.5 TB/s of the 3.66 GB, the five wide levels of C(32,16)
+// 2.70 -> 1.66 ms).  The child's metadata is assembled word-wise (the byte-wise form was a third of the loop's
+// instructions).
+// ---------------------------------------------------------------------------
+// (4 waves per SIMD: 6 changed nothing, 8 spills and is 70 % slower)
+template <int NMXT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_enum_expand_staged(EnumDev d, PrefixDev pd, int t,
+                                                            const double* __restrict__ src, int src_cap,
+                                                            double* __restrict__ dst, int dst_cap, int ppw,
+                                                            unsigned long long begin,
+                                                            unsigned long long end) {
+    constexpr int PGT = 16, RS = 16, GW = 4;
+    constexpr int MAXC = NMXT + PGT + 1;            // columns of a record incl. the rhs: n - t + 1 <= m + NMXT + 1
+    constexpr int PER = (MAXC * RS + META + 63) / 64;   // doubles per lane that hold one record's meaningful part + metadata
+    using Meta = NodeMetaT<PGT>;
+    __shared__ int s_base[kExpandParents];
+    __shared__ int s_last[kExpandParents];
+    __shared__ __attribute__((aligned(16))) double s_rec[4][MAXC * RS + META];
+    // subsets below a child with last column a: C(n-1-a, m-t-1) — one table per level, in LDS (looked up per
+    // child by every parent's lane in phase A and again per lane in the expansion: out of L2 these dependent
+    // little loads, not the records, were what a parent cost)
+    __shared__ unsigned long long s_cnt[kEnumMaxN + 1];
+    const int m = d.m, n = d.n;
+    const int tid = threadIdx.x;
+    if (tid <= kEnumMaxN) s_cnt[tid] = (tid < n) ? binom(d, n - 1 - tid, m - t - 1) : 0ULL;
+    const int lane = tid & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
+    const int wave = tid >> 6;
+    const int nsrc = min(pd.level_counts[t], src_cap);  // (an overflowed level is reported by the host)
+    const int first = blockIdx.x * 4 * ppw;
+    if (first >= nsrc) return;
+    const int lim = n - m + t;  // largest column selectable at depth t
+    __syncthreads();
+    const size_t rdP = rec_doubles_g<PGT>(n, t, d.rs), rdC = rec_doubles_g<PGT>(n, t + 1, d.rs);
+    if (tid < 64) {   // phase A (as in k_enum_expand): children per parent, one slot allocation per block
+        const int node = first + tid;
+        int nch = 0, last = kHole;
+        if (tid < 4 * ppw && node < nsrc) {
+            const Meta* q = reinterpret_cast<const Meta*>(src + (size_t)node * rdP + (size_t)RS * (n - t + 1));
+            last = q->last_col;
+            if (last != kHole) {
+                unsigned long long rb = q->rank_base;
+                for (int a = last + 1; a <= lim; ++a) {
+                    const unsigned long long cnt = s_cnt[a];
+                    if (overlap(rb, cnt, begin, end) != 0ULL) ++nch;
+                    rb += cnt;
+                }
+            }
+        }
+        int incl = nch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&pd.level_counts[t + 1], total);
+        base = __shfl(base, 63, 64);
+        s_base[tid] = base + incl - nch;
+        s_last[tid] = nch > 0 ? last : kHole;   // (a parent without a child in the range is skipped like a hole)
+    }
+    __syncthreads();
+    double* L = s_rec[wave];
+    double pre[PER];
+    // issue the loads of this wave's parent `it` (nothing for a hole or past the end: wave-uniform)
+    auto fetch = [&](int it) {
+        const int local = wave * ppw + it, node = first + local;
+        const int last = (it < ppw && node < nsrc) ? s_last[local] : kHole;
+        if (last == kHole) return;
+        const double* P = src + (size_t)node * rdP;
+        const double* Q = P + (size_t)(last + 1 - t) * RS;
+        const int cnt = (n - last) * RS + META;   // columns last+1 .. n-1, the rhs, and the metadata right behind it
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = u * 64 + lane;
+            pre[u] = idx < cnt ? Q[idx] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < ppw; ++it) {
+        const int local = wave * ppw + it;
+        const int node = first + local;
+        if (node >= nsrc) break;
+        const int last = s_last[local];
+        if (last == kHole) {
+            fetch(it + 1);
+            continue;
+        }
+        const int cnt = (n - last) * RS + META;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = u * 64 + lane;
+            if (idx < cnt) L[idx] = pre[u];
+        }
+        fetch(it + 1);   // the next parent travels while this one is expanded
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nrhs = (n - 1 - last) * RS;   // offset of the rhs column inside L
+        const Meta& pm = *reinterpret_cast<const Meta*>(L + nrhs + RS);   // (read from LDS where needed)
+        // ---- the children, one per lane: subset counts, rank bases (exclusive scan), range overlap
+        const int a_l = last + 1 + lane;
+        const unsigned long long cnt_l = (a_l <= lim) ? s_cnt[a_l] : 0ULL;
+        unsigned long long incl = cnt_l;
+#pragma unroll
+        for (int off = 1; off < (NMXT > 16 ? 64 : 32); off <<= 1) {   // at most NMXT + 1 children
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const unsigned long long rb_l = pm.rank_base + (incl - cnt_l);
+        const unsigned long long ov_l = overlap(rb_l, cnt_l, begin, end);
+        const unsigned long long vmask = __ballot(ov_l != 0ULL);
+        const int nchild = __popcll(vmask);
+        const int wbase = s_base[local];
+        const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
+        const double prhs = L[nrhs + gl];
+        unsigned long long sing = 0ULL;
+        for (int k0 = 0; k0 < nchild; k0 += GW) {
+            const int k = k0 + g;                  // this group's child (k-th valid one)
+            const bool active = k < nchild;        // whole groups are active or not
+            unsigned long long vm = vmask;
+            for (int i = 0; i < (active ? k : 0); ++i) vm &= vm - 1ULL;
+            const int src_lane = active ? (int)__builtin_ctzll(vm) : 0;
+            const int a = last + 1 + src_lane;
+            const unsigned long long rb_child = __shfl(rb_l, src_lane, 64);
+            const unsigned long long ov = __shfl(ov_l, src_lane, 64);
+            const int myslot = wbase + k;
+            // (no wave-level operation below: groups proceed independently)
+            if (!active) continue;
+            if (myslot >= dst_cap) {
+                if (gl == 0) atomicExch(pd.overflow, 1);
+                continue;
+            }
+            double* C = dst + (size_t)myslot * rdC;
+            Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)RS * (n - t));
+            const double* La = L + (a - last - 1) * RS;   // the child's pivot column
+            const double w = La[gl];
+            double big;
+            const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
+            const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
+            if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
+                sing += ov;  // the whole subtree is singular: leave a hole
+                if (gl == 0) cmeta->last_col = kHole;
+                continue;
+            }
+            const double piv = La[p];
+            const double inv = 1.0 / piv;
+            const bool isp = (gl == p);
+            const double lx = isp ? inv : -(w * inv);
+            double* Cc = C + (size_t)(a - t) * RS + gl;   // column c of the child at (c - t - 1) * RS
+            const double* Lc = La + RS;                   // column a + 1 of the parent
+#pragma unroll 2
+            for (int c = a + 1; c < n; ++c, Lc += RS, Cc += RS) *Cc = fma(lx, Lc[p], isp ? -0.0 : Lc[gl]);
+            C[(size_t)(n - t - 1) * RS + gl] = fma(lx, L[nrhs + p], isp ? -0.0 : prhs);
+            if (gl == 0) {
+                // the child's metadata, word-wise (64 bytes: four 16-byte stores; the pivot row / column lists
+                // are the parent's with byte t patched — byte by byte this was a third of the loop's instructions)
+                const uint4 pr4 = *reinterpret_cast<const uint4*>(pm.prow), pc4 = *reinterpret_cast<const uint4*>(pm.pcol);
+                unsigned prw[4] = {pr4.x, pr4.y, pr4.z, pr4.w}, pcw[4] = {pc4.x, pc4.y, pc4.z, pc4.w};
+                const unsigned sh = 8u * (unsigned)(t & 3), keep = ~(0xFFu << sh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q == (t >> 2)) {
+                        prw[q] = (prw[q] & keep) | ((unsigned)p << sh);
+                        pcw[q] = (pcw[q] & keep) | ((unsigned)a << sh);
+                    }
+                uint4* out = reinterpret_cast<uint4*>(cmeta);
+                const unsigned long long mn = (unsigned long long)__double_as_longlong(minp),
+                                         mx = (unsigned long long)__double_as_longlong(maxp);
+                out[0] = make_uint4((unsigned)rb_child, (unsigned)(rb_child >> 32), (unsigned)mn, (unsigned)(mn >> 32));
+                out[1] = make_uint4((unsigned)mx, (unsigned)(mx >> 32), (unsigned)a, pm.used_mask | (1u << p));
+                out[2] = make_uint4(prw[0], prw[1], prw[2], prw[3]);
+                out[3] = make_uint4(pcw[0], pcw[1], pcw[2], pcw[3]);
+            }
+        }
+        if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the slice is rewritten by the next parent)
+    }
+}
+
 // The same expansion for NARROW levels (the first few, and every level of a small rank range):
 // one WAVE per (parent, child) — lane = (row, column quarter) — with all of the child's columns
 // in flight at once.  A lone 16-lane group pivoting up to n-m+1 children one after the other, four
@@ -209,9 +407,15 @@ __global__ __launch_bounds__(256) void k_enum_expand_narrow(EnumDev d, PrefixDev
     const Meta pm = *reinterpret_cast<const Meta*>(P + (size_t)RS * (n - t + 1));
     const int a = pm.last_col + 1 + j;
     if (pm.last_col == kHole || a > n - m + t) return;
-    unsigned long long rb = pm.rank_base;
-    for (int a2 = pm.last_col + 1; a2 < a; ++a2) rb += binom(d, n - 1 - a2, m - t - 1);
-    const unsigned long long ov = overlap(rb, binom(d, n - 1 - a, m - t - 1), begin, end);
+    // subsets below the siblings in front of this child: one lane per sibling and a wave sum (a loop of up to
+    // n - m dependent little loads from the table in L2 was most of a narrow level's 8-60 us)
+    const int a2 = pm.last_col + 1 + lane;
+    unsigned long long part = (a2 < a) ? binom(d, n - 1 - a2, m - t - 1) : 0ULL;
+    const unsigned long long mine = binom(d, n - 1 - a, m - t - 1);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    const unsigned long long rb = pm.rank_base + part;
+    const unsigned long long ov = overlap(rb, mine, begin, end);
     if (ov == 0ULL) return;
     int slot = 0;
     if (lane == 0) slot = atomicAdd(&pd.level_counts[t + 1], 1);
@@ -490,7 +694,12 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
         const int groups_per_block = 4 * ppw;
         // narrow levels: one wave per (parent, child)
         const uint64_t waves = bound * (uint64_t)(n - m + 1);
-        const bool narrow = waves <= (uint64_t)ctx->num_cus * 128;
+        // (every child of a narrow level takes its slot with a returning atomic of its own, ~11 ns each on the one
+        // counter: beyond a few thousand candidate waves the per-parent kernels, one allocation per block, are faster —
+        // 16-row records: the LDS-staged kernel expands the 969 parents of C(32,16)'s level 3 in a fraction of the
+        // 61 us the narrow form took for their 4845 children)
+        static const int narrow_mult = getenv("LP_ENUM_NARROW_MULT") ? atoi(getenv("LP_ENUM_NARROW_MULT")) : (pg == 16 ? 16 : 128);
+        const bool narrow = waves <= (uint64_t)ctx->num_cus * (uint64_t)narrow_mult;
         const unsigned grid = narrow ? (unsigned)lp_ceil_div<uint64_t>(waves, 4)
                                      : (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block);
         const double* src = p->prefix_buf[cur];
@@ -506,7 +715,13 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
             hipLaunchKernelGGL((k_enum_expand<PGT, NMXT>), grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap,   \
                                ppw, b, e);                                                                     \
     } while (0)
-        if (shape == 1) LP_EXPAND(16, 16);
+        // wide levels of 16-row records: the parent staged in LDS (LP_ENUM_EXPAND_UNSTAGED=1: the earlier kernel, A/B)
+        static const bool unstaged = getenv("LP_ENUM_EXPAND_UNSTAGED") != nullptr;
+        if (shape == 1 && !narrow && !unstaged)
+            hipLaunchKernelGGL(k_enum_expand_staged<16>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
+        else if (shape == 2 && !narrow && !unstaged)
+            hipLaunchKernelGGL(k_enum_expand_staged<57>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
+        else if (shape == 1) LP_EXPAND(16, 16);
         else if (shape == 2) LP_EXPAND(16, 57);
         else LP_EXPAND(32, 32);
 #undef LP_EXPAND
