@@ -637,7 +637,7 @@ uint64_t lp_binom(int n, int k) { return lp_host_binom(n, k); }
 
 // Cost-balanced cut of the rank space (same rule as simplexmethod_amd/dist.py:
 // balanced_shard_bounds): cost(x) = x + kShardRecordCost * (depth m-7 tree nodes before subset x).
-static const uint64_t kShardRecordCost = 200;
+static const uint64_t kShardRecordCost = 160;
 int lp_enum_shard_bounds(int n, int m, int shard, int shards, uint64_t* begin_out, uint64_t* end_out) {
     if (!begin_out || !end_out || shards <= 0 || shard < 0 || shard >= shards) return LP_BAD_ARG;
     if (m <= 0 || n < m || n > kEnumMaxN || m > kEnumMaxM) return LP_BAD_ARG;

@@ -14,7 +14,8 @@
 //            through HBM (D0 = m-7 for the default second phase).  One wave per parent, its
 //            four 16-lane groups (lane = row) pivot four children at a time and write the child
 //            records; a block of 64 parents takes all its children's slots with one atomic.
-//            Narrow levels: one wave per (parent, child).  Bandwidth-shaped (7 GB for C(32,16)).
+//            Narrow levels: one wave per (parent, child).  Wide levels of 16-row records:
+//            k_enum_expand_staged (parent record and the subset-count table in LDS).
 //   phase 2  the leaf kernels of enum_leaf.hip (one lane per subset from the depth
 //            m-7 records, with one or two more pivots done by the wave in LDS).
 //   Feasible subsets are rare; each is appended to a list as (rank, record index) and its objective
@@ -56,8 +57,13 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     // take 5 rounds of dependent HBM round trips instead of 17, with four children's stores in
     // flight together.
     __shared__ int s_base[kExpandParents];
+    // subsets below a child with last column a, C(n-1-a, m-t-1): the level's column of the binomial table, in LDS
+    // (round 3: looked up in L2 child by child these dependent little loads were what a parent cost — see
+    // k_enum_expand_staged below)
+    __shared__ unsigned long long s_cnt[kEnumMaxN + 1];
     const int m = d.m, n = d.n;
     const int tid = threadIdx.x;
+    if (tid <= kEnumMaxN) s_cnt[tid] = (tid < n) ? binom(d, n - 1 - tid, m - t - 1) : 0ULL;
     constexpr int GW = 64 / PGT;   // groups (children in flight) per wave
     using Meta = NodeMetaT<PGT>;
     const int RS = rec_rs<PGT>(d.rs);   // row stride of the records' columns
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     const int first = blockIdx.x * 4 * ppw;
     if (first >= nsrc) return;
     const int lim = n - m + t;  // largest column selectable at depth t
+    __syncthreads();
     if (tid < 64) {
         const int node = first + tid;
         int nch = 0;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
             if (last != kHole) {
                 unsigned long long rb = q->rank_base;
                 for (int a = last + 1; a <= lim; ++a) {
-                    const unsigned long long cnt = binom(d, n - 1 - a, m - t - 1);
+                    const unsigned long long cnt = s_cnt[a];
                     if (overlap(rb, cnt, begin, end) != 0ULL) ++nch;
                     rb += cnt;
                 }
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
     if (pm.last_col == kHole) continue;
     // ---- the children, one per lane: subset counts, rank bases (exclusive scan), range overlap
     const int a_l = pm.last_col + 1 + lane;
-    const unsigned long long cnt_l = (a_l <= lim) ? binom(d, n - 1 - a_l, m - t - 1) : 0ULL;
+    const unsigned long long cnt_l = (a_l <= lim) ? s_cnt[a_l] : 0ULL;
     unsigned long long incl = cnt_l;
 #pragma unroll
     for (int off = 1; off < (NMXT > 16 ? 64 : 32); off <<= 1) {   // at most NMXT + 1 children

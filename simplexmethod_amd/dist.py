@@ -78,7 +78,7 @@ def _lexrank(universe, subset):
     return r
 
 
-RECORD_COST = 200  # one depth m-7 tree node costs about as much as 200 subsets (scripts/scan_record_cost.py, MI355X; 170 before the round-3 leaf kernels)
+RECORD_COST = 160  # one depth m-7 tree node costs about as much as 160 subsets (scripts/scan_record_cost.py, MI355X, on the round-3 kernels)
 
 
 def balanced_shard_bounds(n, m, rank, world, record_cost=RECORD_COST):
