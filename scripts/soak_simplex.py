@@ -40,7 +40,7 @@ def main():
         maximize = bool(rng.integers(0, 2))
         max_iter = int(rng.choice([50, 400, 5000]))
         got = []
-        for algo in (capi.SIMPLEX_RESIDENT, capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD):
+        for algo in (capi.SIMPLEX_RESIDENT, capi.SIMPLEX_LAUNCH, capi.SIMPLEX_LOOKAHEAD, capi.SIMPLEX_OVERLAP):
             p = ctx.simplex_problem(A, b, c, basis, maximize, no)
             rc, st = p.run(max_iter=max_iter, algo=algo)
             d = p.download(trace_cap=min(st.pivots, 5000), want_tableau=True)

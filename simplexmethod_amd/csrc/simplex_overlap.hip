@@ -239,14 +239,25 @@ size_t lp_overlap_lds_bytes(int m) { return 2 * sizeof(double) * (size_t)(m + 2)
 // The shape runs on this path if the selector's two m-vectors fit one CU's LDS.
 bool lp_overlap_fits(int m) { return lp_overlap_lds_bytes(m) <= 156 * 1024; }
 
+// Second tableau and second eta slot, on first use (each checked on its own: a failed second allocation must not
+// leave a later call with the first one only).  AUTO calls this before it commits to the algorithm: without the
+// memory for a second tableau it takes the launch pair per pivot instead.
+int lp_overlap_prepare(lp_simplex_problem* p) {
+    lp_context* ctx = p->ctx;
+    const SimplexDev& d = p->dev;
+    if (!lp_overlap_fits(d.m)) LP_FAIL(ctx, LP_BAD_ARG, "overlapped simplex: m too large for the selector's LDS");
+    if (!p->ov_T) LP_HIP(ctx, hipMalloc(&p->ov_T, p->tableau_bytes));
+    if (!p->ov_vec) LP_HIP(ctx, hipMalloc(&p->ov_vec, sizeof(double) * ((size_t)d.m + 2 + (size_t)d.ld) + 64));
+    return LP_OPTIMAL;
+}
+
 int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats) {
     lp_context* ctx = p->ctx;
     const SimplexDev& d = p->dev;
     hipStream_t s = ctx->stream;
-    if (!lp_overlap_fits(d.m)) LP_FAIL(ctx, LP_BAD_ARG, "overlapped simplex: m too large for the selector's LDS");
-    if (!p->ov_T) {   // second tableau, second eta slot: on first use
-        LP_HIP(ctx, hipMalloc(&p->ov_T, p->tableau_bytes));
-        LP_HIP(ctx, hipMalloc(&p->ov_vec, sizeof(double) * ((size_t)d.m + 2 + (size_t)d.ld) + 64));
+    {
+        const int rc = lp_overlap_prepare(p);
+        if (rc) return rc;
     }
     OverlapDev ov;
     ov.T[0] = d.T;
