@@ -391,6 +391,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
 }
 
+// The staged expansion for 32-ROW records (m > 16; RS = m rounded up to even rows per column, two 32-lane groups =
+// two children per wave at a time).  A record's meaningful part is up to 65 columns x 32 rows = 16.6 KB: no
+// register prefetch of the next parent here (it would take 66 VGPRs) — the wave copies its parent to LDS at the
+// top of each iteration, eight doubles per lane in flight at a time, and pays that one round trip per parent
+// instead of the ~4 per round of k_enum_expand.
+template <int NMXT>
+__global__ __launch_bounds__(256) void k_enum_expand_staged32(EnumDev d, PrefixDev pd, int t,
+                                                              const double* __restrict__ src, int src_cap,
+                                                              double* __restrict__ dst, int dst_cap, int ppw,
+                                                              unsigned long long begin,
+                                                              unsigned long long end) {
+    constexpr int PGT = 32, GW = 2;
+    constexpr int MAXC = NMXT + PGT + 1;   // columns of a record incl. the rhs: n - t + 1 <= m + NMXT + 1
+    using Meta = NodeMetaT<PGT>;
+    constexpr int METAD = sizeof(Meta) / 8;
+    __shared__ int s_base[kExpandParents];
+    __shared__ int s_last[kExpandParents];
+    __shared__ __attribute__((aligned(16))) double s_rec[4][MAXC * PGT + METAD];
+    __shared__ unsigned long long s_cnt[kEnumMaxN + 1];   // C(n-1-a, m-t-1) by child column a
+    const int m = d.m, n = d.n;
+    const int RS = rec_rs<PGT>(d.rs);
+    const int tid = threadIdx.x;
+    if (tid <= kEnumMaxN) s_cnt[tid] = (tid < n) ? binom(d, n - 1 - tid, m - t - 1) : 0ULL;
+    const int lane = tid & 63, gl = lane & (PGT - 1), g = lane / PGT, gbase = lane & ~(PGT - 1);
+    const int wave = tid >> 6;
+    const int nsrc = min(pd.level_counts[t], src_cap);
+    const int first = blockIdx.x * 4 * ppw;
+    if (first >= nsrc) return;
+    const int lim = n - m + t;
+    __syncthreads();
+    const size_t rdP = rec_doubles_g<PGT>(n, t, d.rs), rdC = rec_doubles_g<PGT>(n, t + 1, d.rs);
+    if (tid < 64) {   // phase A (as in k_enum_expand)
+        const int node = first + tid;
+        int nch = 0, last = kHole;
+        if (tid < 4 * ppw && node < nsrc) {
+            const Meta* q = reinterpret_cast<const Meta*>(src + (size_t)node * rdP + (size_t)RS * (n - t + 1));
+            last = q->last_col;
+            if (last != kHole) {
+                unsigned long long rb = q->rank_base;
+                for (int a = last + 1; a <= lim; ++a) {
+                    const unsigned long long cnt = s_cnt[a];
+                    if (overlap(rb, cnt, begin, end) != 0ULL) ++nch;
+                    rb += cnt;
+                }
+            }
+        }
+        int incl = nch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&pd.level_counts[t + 1], total);
+        base = __shfl(base, 63, 64);
+        s_base[tid] = base + incl - nch;
+        s_last[tid] = nch > 0 ? last : kHole;
+    }
+    __syncthreads();
+    double* L = s_rec[wave];
+    const bool row = gl < RS;   // this lane holds a row of the record
+    for (int it = 0; it < ppw; ++it) {
+        const int local = wave * ppw + it;
+        const int node = first + local;
+        if (node >= nsrc) break;
+        const int last = s_last[local];
+        if (last == kHole) continue;
+        {   // the parent's columns last+1 .. n-1, rhs and metadata (contiguous) -> LDS, eight doubles per lane in flight
+            const double* Q = src + (size_t)node * rdP + (size_t)(last + 1 - t) * RS;
+            const int cnt = (n - last) * RS + METAD;
+            for (int base = 0; base < cnt; base += 8 * 64) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 64 + lane;
+                    v[u] = idx < cnt ? Q[idx] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 64 + lane;
+                    if (idx < cnt) L[idx] = v[u];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nrhs = (n - 1 - last) * RS;
+        const Meta& pm = *reinterpret_cast<const Meta*>(L + nrhs + RS);
+        const int a_l = last + 1 + lane;
+        const unsigned long long cnt_l = (a_l <= lim) ? s_cnt[a_l] : 0ULL;
+        unsigned long long incl = cnt_l;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const unsigned long long rb_l = pm.rank_base + (incl - cnt_l);
+        const unsigned long long ov_l = overlap(rb_l, cnt_l, begin, end);
+        const unsigned long long vmask = __ballot(ov_l != 0ULL);
+        const int nchild = __popcll(vmask);
+        const int wbase = s_base[local];
+        const bool prow_used = (gl >= m) || ((pm.used_mask >> gl) & 1u);
+        const double prhs = row ? L[nrhs + gl] : 0.0;
+        unsigned long long sing = 0ULL;
+        for (int k0 = 0; k0 < nchild; k0 += GW) {
+            const int k = k0 + g;
+            const bool active = k < nchild;
+            unsigned long long vm = vmask;
+            for (int i = 0; i < (active ? k : 0); ++i) vm &= vm - 1ULL;
+            const int src_lane = active ? (int)__builtin_ctzll(vm) : 0;
+            const int a = last + 1 + src_lane;
+            const unsigned long long rb_child = __shfl(rb_l, src_lane, 64);
+            const unsigned long long ov = __shfl(ov_l, src_lane, 64);
+            const int myslot = wbase + k;
+            // pick_pivot_row_g<32> exchanges between the two halves of a group: called by whole groups only, but a
+            // group that is not active must still reach it together with the other one (wave-level shuffle)
+            const double* La = L + (size_t)(active ? a - last - 1 : 0) * RS;
+            const double w = row ? La[gl] : 0.0;
+            double big;
+            const int p = pick_pivot_row_g<PGT>(w, prow_used, gbase, big);
+            if (!active) continue;
+            if (myslot >= dst_cap) {
+                if (gl == 0) atomicExch(pd.overflow, 1);
+                continue;
+            }
+            double* C = dst + (size_t)myslot * rdC;
+            Meta* cmeta = reinterpret_cast<Meta*>(C + (size_t)RS * (n - t));
+            const double minp = fmin(pm.minp, big), maxp = fmax(pm.maxp, big);
+            if (!(big > 0.0) || minp <= DBL_EPSILON * (double)m * maxp) {
+                sing += ov;
+                if (gl == 0) cmeta->last_col = kHole;
+                continue;
+            }
+            const double piv = La[p];
+            const double inv = 1.0 / piv;
+            const bool isp = (gl == p);
+            const double lx = isp ? inv : -(w * inv);
+            double* Cc = C + (size_t)(a - t) * RS + gl;
+            const double* Lc = La + RS;
+            if (row) {
+#pragma unroll 2
+                for (int c = a + 1; c < n; ++c, Lc += RS, Cc += RS) *Cc = fma(lx, Lc[p], isp ? -0.0 : Lc[gl]);
+                C[(size_t)(n - t - 1) * RS + gl] = fma(lx, L[nrhs + p], isp ? -0.0 : prhs);
+            }
+            if (gl == 0) {
+                Meta cm = pm;   // (32-row records: 96 bytes, copied as a struct)
+                cm.rank_base = rb_child;
+                cm.minp = minp;
+                cm.maxp = maxp;
+                cm.last_col = a;
+                cm.used_mask = pm.used_mask | (1u << p);
+                cm.prow[t] = (unsigned char)p;
+                cm.pcol[t] = (unsigned char)a;
+                *cmeta = cm;
+            }
+        }
+        if (gl == 0 && sing) atomicAdd(&d.result->counts[2], sing);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // The same expansion for NARROW levels (the first few, and every level of a small rank range):
 // one WAVE per (parent, child) — lane = (row, column quarter) — with all of the child's columns
 // in flight at once.  A lone 16-lane group pivoting up to n-m+1 children one after the other, four
@@ -705,7 +868,7 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
         // counter: beyond a few thousand candidate waves the per-parent kernels, one allocation per block, are faster —
         // 16-row records: the LDS-staged kernel expands the 969 parents of C(32,16)'s level 3 in a fraction of the
         // 61 us the narrow form took for their 4845 children)
-        static const int narrow_mult = getenv("LP_ENUM_NARROW_MULT") ? atoi(getenv("LP_ENUM_NARROW_MULT")) : (pg == 16 ? 16 : 128);
+        const int narrow_mult = getenv("LP_ENUM_NARROW_MULT") ? atoi(getenv("LP_ENUM_NARROW_MULT")) : (pg == 16 ? 16 : 128);   // (env: A/B, tests)
         const bool narrow = waves <= (uint64_t)ctx->num_cus * (uint64_t)narrow_mult;
         const unsigned grid = narrow ? (unsigned)lp_ceil_div<uint64_t>(waves, 4)
                                      : (unsigned)lp_ceil_div<uint64_t>(bound, groups_per_block);
@@ -723,11 +886,13 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
                                ppw, b, e);                                                                     \
     } while (0)
         // wide levels of 16-row records: the parent staged in LDS (LP_ENUM_EXPAND_UNSTAGED=1: the earlier kernel, A/B)
-        static const bool unstaged = getenv("LP_ENUM_EXPAND_UNSTAGED") != nullptr;
+        const bool unstaged = getenv("LP_ENUM_EXPAND_UNSTAGED") != nullptr;
         if (shape == 1 && !narrow && !unstaged)
             hipLaunchKernelGGL(k_enum_expand_staged<16>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
         else if (shape == 2 && !narrow && !unstaged)
             hipLaunchKernelGGL(k_enum_expand_staged<57>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
+        else if (shape == 3 && !narrow && !unstaged)
+            hipLaunchKernelGGL(k_enum_expand_staged32<32>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
         else if (shape == 1) LP_EXPAND(16, 16);
         else if (shape == 2) LP_EXPAND(16, 57);
         else LP_EXPAND(32, 32);

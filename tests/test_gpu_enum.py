@@ -786,3 +786,25 @@ def test_prefix_fast_and_plain_division_agree(ctx, m, n, seed, monkeypatch):
     assert q.range(0, total, capi.ENUM_PREFIX)[:3] == ref and q.exact_division
     assert q.first_within(0, total, ref[1]) == k
     q.free()
+
+
+@pytest.mark.parametrize("m,n,seed", [(16, 24, 21), (12, 26, 22), (9, 30, 23), (16, 32, 24)])
+def test_prefix_level_kernels_agree(ctx, m, n, seed, monkeypatch):
+    """The breadth-first levels in their three forms — parent staged in LDS (default for wide levels of 16-row
+    records), operands fetched from the record (LP_ENUM_EXPAND_UNSTAGED=1), one wave per child (every level
+    narrow: LP_ENUM_NARROW_MULT large) — build the same records: counts, optimum and tie-rule rank of a range
+    are identical, and equal to the direct kernel's."""
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    lo, hi = total // 7, min(total, total // 7 + (1 << 22))
+    p = ctx.enum_problem(A, b, c, True)
+    ref = p.range(lo, hi, capi.ENUM_PREFIX)[:3]
+    k = p.first_within(lo, hi, ref[1]) if ref[0] == 0 else None
+    assert p.range(lo, hi, capi.ENUM_DIRECT)[:3] == ref
+    for var, val in (("LP_ENUM_EXPAND_UNSTAGED", "1"), ("LP_ENUM_NARROW_MULT", "100000000")):
+        monkeypatch.setenv(var, val)
+        assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref, var
+        if k is not None:
+            assert p.first_within(lo, hi, ref[1]) == k
+        monkeypatch.delenv(var)
+    p.free()
