@@ -1398,12 +1398,18 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             if (thin_order >= 1) LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[1], 0));
         }
         if (thin_order == 1) launch_thin();
+        // both leaf kernels with resident-sized grids (3 workgroups per CU).  (2 for table 1's kernel gives the best
+        // single passes — C(28,14) 1.17 against 1.19 ms, C(32,16) 13.2 against 13.3 — but half of the passes then take
+        // 14.0-14.1 ms: the average is worse.  LP_ENUM_GRID2 / LP_ENUM_GRID1: workgroups per CU, A/B.)
+        int grid2 = grid6, grid1 = grid6;
+        if (const char* ev = getenv("LP_ENUM_GRID2")) grid2 = ctx->num_cus * std::max(1, atoi(ev));   // (A/B: workgroups per CU)
+        if (const char* ev = getenv("LP_ENUM_GRID1")) grid1 = ctx->num_cus * std::max(1, atoi(ev));
         if (exact) {
-            hipLaunchKernelGGL((k_enum_leaves<2, true>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
-            hipLaunchKernelGGL((k_enum_leaves<1, true>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<2, true>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<1, true>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         } else {
-            hipLaunchKernelGGL((k_enum_leaves<2, false>), grid6, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
-            hipLaunchKernelGGL((k_enum_leaves<1, false>), grid6, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<2, false>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<1, false>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         }
         if (thin_order >= 2) launch_thin();
         if (side) {
