@@ -89,7 +89,7 @@ enum {
     LP_SIMPLEX_ALGO_LAUNCH = 1,    /* one select + one rank-1-update launch per pivot   */
     LP_SIMPLEX_ALGO_LOOKAHEAD = 2, /* J pivots staged by a one-workgroup selector, then
                                       one rank-J update pass over the tableau            */
-    LP_SIMPLEX_ALGO_RESIDENT = 3   /* one launch per solve: the tableau stays in the registers of
+    LP_SIMPLEX_ALGO_RESIDENT = 3,  /* one launch per solve: the tableau stays in the registers of
                                       co-resident workgroups, one per CU (32 columns each for
                                       m <= 512, 16 columns each for 512 < m <= 960; at most 256
                                       workgroups, i.e. n <= 8192 resp. n <= 4096), one all-to-all
@@ -97,7 +97,6 @@ enum {
                                       hand-off that times out (the workgroups never became
                                       co-resident) re-runs the solve on another algorithm:
                                       lp_simplex_stats::fell_back                          */
-    ,
     LP_SIMPLEX_ALGO_OVERLAP = 4    /* one launch per pivot: the rank-1 update of pivot k streams the
                                       tableau out of place while one more workgroup of the same launch
                                       selects pivot k+1 from the old tableau and pivot k's eta; shapes
