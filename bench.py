@@ -418,6 +418,29 @@ def enum_wide_leg(ctx):
     return out
 
 
+def enum_config2_leg(ctx):
+    """BASELINE configs[2]: vertex enumeration n = 28, m = 14 (C(28,14) = 40.1 M subsets) on one GPU, seed 0:
+    pass 1 + tie rule, device-resident problem, best of 5; an eighth-of-C(32,16)-sized problem, so the fixed
+    costs of a pass weigh as they do on an 8-way shard."""
+    from simplexmethod_amd import capi
+    m, n = 14, 28
+    A, b, c, _ = capi.gen_lp(0, m, n)
+    p = ctx.enum_problem(A, b, c, True)
+    p.range(0, p.total)
+    best, kern = 1e9, 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        rc, z, counts, st = p.range(0, p.total)
+        k = p.first_within(0, p.total, z) if rc == 0 else None
+        best = min(best, time.perf_counter() - t0)
+        kern = min(kern, st.kernel_ms)
+    out = {"workload": f"vertex enumeration C({n},{m}) = {p.total} subsets, seed 0 (BASELINE configs[2])",
+           "ms": round(1e3 * best, 3), "kernel_ms": round(kern, 3), "subsets_per_s": round(p.total / best, 1),
+           "status": int(rc), "optimum": z, "rank": k, "counts": list(counts)}
+    p.free()
+    return out
+
+
 def two_phase_leg(ctx, args):
     """a Symmetrical-style MIN problem (no starting basis) through
     lp_simplex_two_phase; host-buffer entry point, so the time includes both uploads."""
@@ -640,6 +663,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_batched:
         line["enum"]["other_inputs"] = enum_inputs_leg(ctx, args)
         line["enum"]["wide_shapes"] = enum_wide_leg(ctx)
+        line["enum"]["config2_c28_14"] = enum_config2_leg(ctx)
         line["enum"]["worst_case_subsets_per_s"] = min(r.get("first_call_subsets_per_s", r["subsets_per_s"])
                                                        for r in line["enum"]["other_inputs"])
     if rank == 0 and not args.no_batched:
