@@ -64,12 +64,6 @@ for rnd in range(2):
     best, st = best_of(p, capi.SIMPLEX_RESIDENT)
     del os.environ["LP_RESIDENT_PUBL"]
     print("resident (eta column published)        : best solve_ms=%.4f -> %.3f us/pivot" % (best, 1e3 * best / st.pivots), flush=True)
-    os.environ["LP_RESIDENT_V1"] = "1"
-    p1 = ctx.simplex_problem(A, b, c, basis, True, 512)
-    del os.environ["LP_RESIDENT_V1"]
-    best, st = best_of(p1, capi.SIMPLEX_RESIDENT)
-    p1.free()
-    print("round-2 kernel                 : best solve_ms=%.4f -> %.3f us/pivot" % (best, 1e3 * best / st.pivots), flush=True)
 best, st = best_of(p, capi.SIMPLEX_LOOKAHEAD, 5)
 print("lookahead: best solve_ms=%.3f -> %.3f us/pivot" % (best, 1e3 * best / st.pivots), flush=True)
 A2, b2, c2, basis2 = lpcases.random_lp(41, 768, 1536)

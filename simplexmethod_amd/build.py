@@ -121,7 +121,7 @@ def build_cpp_tests(force=False, verbose=False):
         exe = os.path.join(TESTS_OUT, os.path.splitext(os.path.basename(src))[0])
         deps = [src, host, HIP_LIB] + _sources(TESTS_CPP, (".h",)) + _sources(HOST, (".h",))
         if force or not _newer(exe, deps):
-            cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", HOST, "-I", TESTS_CPP,
+            cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-DLP_HOST_TEST_HOOKS", "-I", INCLUDE, "-I", HOST, "-I", TESTS_CPP,
                    "-o", exe, src, "-L", OUT, "-lsimplexmethod_host", "-lsimplexmethod_hip",
                    "-pthread", "-Wl,-rpath,$ORIGIN/../../../simplexmethod_amd/_build"]
             if verbose:

@@ -935,10 +935,6 @@ static int batched_reg_launch(lp_context* ctx, const BatchedDev& d) {
     size_t shm = dbl * 8 + sizeof(int) * (size_t)(nn + d.m + d.n);
     shm = (shm + 15) & ~(size_t)15;
     shm += 16 + sizeof(double) * (size_t)batched_stage_cols(d.m) * (size_t)batched_stage_stride(d.m);   // staging of the initial tableau
-    if (const char* e = getenv("LP_BATCHED_MIN_LDS_KB")) {   // experiments: fewer LPs per CU (84: one, 54: two, 40: three)
-        const size_t want = (size_t)atoi(e) * 1024;
-        if (shm < want) shm = want;
-    }
     LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_batched_simplex_reg<NT, RPT, DREG, STAMPS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL((k_batched_simplex_reg<NT, RPT, DREG, STAMPS>), d.batch, NT, shm, ctx->stream, d);
@@ -960,15 +956,15 @@ int lp_batched_launch(lp_context* ctx, const BatchedDev& d) {
             return batched_reg_launch<512, 44, true, true>(ctx, d);
         LP_FAIL(ctx, LP_BAD_ARG, "LP_BATCHED_STAMPS=reg: the shape does not take the 512-thread register form");
     }
-    if (!d.stamps && !getenv("LP_BATCHED_LDS")) {   // (LP_BATCHED_LDS: A/B against the LDS form)
+    if (!d.stamps) {
         // Register-resident form, smallest row array that holds the shape.  Shapes with many rows per
         // thread take the 512-thread form first: two workgroups (two LPs) then share a CU and one LP's
         // one-wave scans run under the other's update (128 x 256: 3.24 ms against 3.63 ms for the
-        // 1024-thread form and 4.02 ms for the LDS form; LP_BATCHED_1024 forces the 1024-thread form).
+        // 1024-thread form and 4.02 ms for the LDS form).
         const int rpt = batched_reg_rpt<1024>(d.m, d.n), rpt2 = batched_reg_rpt<512>(d.m, d.n);
         if (rpt >= 1 && rpt <= 4) return batched_reg_launch<1024, 4, true>(ctx, d);
         if (rpt >= 1 && rpt <= 12) return batched_reg_launch<1024, 12, true>(ctx, d);
-        if (rpt2 >= 1 && rpt2 <= 44 && !getenv("LP_BATCHED_1024")) return batched_reg_launch<512, 44, true>(ctx, d);
+        if (rpt2 >= 1 && rpt2 <= 44) return batched_reg_launch<512, 44, true>(ctx, d);
         if (rpt >= 1 && rpt <= 20) return batched_reg_launch<1024, 20, true>(ctx, d);
     }
     const size_t shm = lp_batched_lds_bytes(d.m, d.n, nullptr);

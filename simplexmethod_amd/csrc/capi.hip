@@ -230,8 +230,7 @@ int lp_simplex_upload(lp_context* ctx, const double* A, int m, int n, const doub
     la.J = lp_lookahead_pick_j(m, n);
     la.rows_pad = ((m + 1 + 7) / 8) * 8;
     const size_t J = (size_t)(la.J > 0 ? la.J : 1);
-    p->res_v1 = getenv("LP_RESIDENT_V1") != nullptr;   // A/B against the round-2 kernel
-    const bool resident = (p->res_v1 ? lp_resident_plan_v1(m, n, &p->res) : lp_resident_plan(m, n, &p->res)) != 0;
+    const bool resident = lp_resident_plan(m, n, &p->res) != 0;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -383,6 +382,7 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
         algo = LP_SIMPLEX_ALGO_LAUNCH;
     }
     const int asked = algo;
+    p->last_algo = algo;   // (every path overwrites it with the algorithm that answered; an early error return reports the one asked for)
     int rc;
     switch (algo) {
         case LP_SIMPLEX_ALGO_RESIDENT:
@@ -513,8 +513,12 @@ int lp_simplex_two_phase(lp_context* ctx, const double* A, int m, int n, const d
     std::vector<int> N((size_t)m);
     int it[3] = {0, 0, 0};
     if (iters_out) std::memcpy(iters_out, it, sizeof(it));
-    // LP_TWO_PHASE_TRACE=1: wall time of each stage on stderr (diagnostic)
-    const bool trace = getenv("LP_TWO_PHASE_TRACE") != nullptr;
+    // -DLP_TWO_PHASE_TRACE (diagnostic builds, scripts/two_phase_trace.py): wall time of each stage on stderr
+#ifdef LP_TWO_PHASE_TRACE
+    const bool trace = true;
+#else
+    const bool trace = false;
+#endif
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_prev = now();
     auto stage = [&](const char* name) {

@@ -515,7 +515,7 @@ int lp_enum_queue_list_tail(lp_enum_problem* p, double tol, const double* record
     const PrefixDev& pd = p->prefix;
     const size_t shm = enum_smem_bytes(d);
     const unsigned grid = (unsigned)ctx->num_cus * 2;
-    if (records && getenv("LP_ENUM_EVAL_DIRECT") == nullptr)   // (A/B: from-scratch solves)
+    if (records)
         lp_enum_queue_record_eval(p, records);
     else if (d.m <= 16)
         hipLaunchKernelGGL((k_enum_eval_list<16>), grid, 256, shm, ctx->stream, d, pd.list, 0ULL,

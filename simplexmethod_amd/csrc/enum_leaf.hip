@@ -102,9 +102,14 @@ __device__ __forceinline__ double recip_midrange(double x) {
 }
 constexpr double kRecipLo = 0x1p-500, kRecipHi = 0x1p500;
 
-// FAST: every division is recip_midrange(pivot); *redo is set if some pivot magnitude lay outside its range
-// (and the subset is not singular by a zero / NaN pivot anyway, which is decided before any quotient is
-// used) — the caller then repeats the subset with FAST = false (leaf_verdict below).
+// FAST: every division is recip_midrange(pivot); *redo is set if a pivot of THIS function that is a number other
+// than zero lay outside its range — whatever the verdict: every later pivot, and with it `sing`, then rests on
+// quotients that may differ from the division's — and the caller repeats the pass with FAST = false
+// (leaf_verdict below).  Tracked as maxp > 2^500 or max |1/pivot| > 2^500: a zero / NaN pivot has a NaN
+// reciprocal, which v_max_f64 drops, and everything behind it is NaN as well (every later `big` stays at its
+// initial -1), so the garbage behind a zero pivot — whose verdict, singular, is final and exact — never raises
+// the flag; the pivots in front of the first out-of-range one are the division's bits.  (The prefix's pivots
+// were divided plainly by the level kernels; a huge one, through maxp0, raises the flag all the same.)
 template <int KD, int STRIDE, bool PERM, bool OBJ, bool FAST, bool TAB>
 __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&c)[KD], int R, const int (&U)[KD],
                                                  unsigned used, double minp0, double maxp0, int m,
@@ -208,6 +213,7 @@ __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&
     // no per-element "is this the pivot row" selects, and the 2x2 block is the last two rows.
     double PR[KD - 2][KD], PRH[KD - 2], INV[KD - 2];
     double minp = minp0, maxp = maxp0;
+    double maxinv = 0.0;   // FAST: largest |reciprocal of a pivot| of this function
     bool sing = false;
 #pragma unroll
     for (int t = 0; t < KD - 2; ++t) {
@@ -222,7 +228,11 @@ __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&
 #pragma unroll
             for (int r = KD - 1; r >= t; --r) p = (fabs(E[r][t]) == big) ? r : p;   // descending: the first wins
         }
-        if (!(big > 0.0)) sing = true;
+        // (FAST: no test here — a zero column leaves big = 0, a NaN column -1, so minp <= 0 and the threshold
+        // test behind the 2x2 block says singular: one compare per step less in the leaf kernels' hot loop)
+        if constexpr (!FAST) {
+            if (!(big > 0.0)) sing = true;
+        }
         minp = fmin(minp, big);
         maxp = fmax(maxp, big);
         // rotate row p to position t (columns t..KD-1 and the rhs)
@@ -247,6 +257,7 @@ __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&
         // the pivot element, now in its static position (PERM, step 0: its reciprocal is already there)
         const double inv = (PERM && t == 0) ? inv0 : recip(E[t][t]);
         INV[t] = inv;
+        if constexpr (FAST) maxinv = fmax(maxinv, fabs(inv));
 #pragma unroll
         for (int cc = t + 1; cc < KD; ++cc) PR[t][cc] = E[t][cc];
         PRH[t] = H[t];
@@ -281,7 +292,10 @@ __device__ __forceinline__ int leaf_verdict_impl(const double* tab, const int (&
     minp = fmin(minp, fmin(big1, big2));
     maxp = fmax(maxp, fmax(big1, big2));
     if (minp <= DBL_EPSILON * (double)m * maxp) sing = true;
-    if constexpr (FAST) *redo = !sing && !(minp >= kRecipLo && maxp <= kRecipHi);
+    if constexpr (FAST) {
+        maxinv = fmax(maxinv, fmax(fabs(inv1), fabs(inv2)));
+        *redo = maxp > kRecipHi || maxinv > 1.0 / kRecipLo;
+    }
     bool feas = (xa >= -1e-9) && (xb >= -1e-9);
     // the rows pivoted in phase 1: back-substitution
     double xr[OBJ ? KD - 2 : 1];
@@ -1316,7 +1330,7 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         return LP_OPTIMAL;
     };
     const bool exact = p->exact_div;   // plain divisions (a pass of the fast kernels reported pivots out of range)
-    const bool general = shape != 1 || dense || (fused && getenv("LP_ENUM_GENERIC"));   // (env: A/B on a tuned shape)
+    const bool general = shape != 1 || dense;
     if (general) {
         // one item per started run of kGenChunk subsets of a record
         int rc = ensure(pd.items, pd.item_cap, (end - begin) / kGenChunk + (uint64_t)bound + 1024);
@@ -1365,45 +1379,32 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             for (hipEvent_t& ev : ctx->aux_event) LP_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
         hipStream_t s = ctx->stream, sT = ctx->aux_stream[0], s1 = ctx->aux_stream[1];
-        const bool side = getenv("LP_ENUM_ONE_STREAM") == nullptr;   // (A/B: everything on the library's stream)
-        if (!side) sT = s1 = s;
-        int lanes = bound < 300000 ? kItemLanesNarrow : kItemLanesWide;
-        if (const char* ev = getenv("LP_ENUM_ITEM_LANES")) lanes = atoi(ev) == 4 ? 4 : 8;   // (A/B)
-        if (side) {
-            LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
-            LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
-        }
+        const int lanes = bound < 300000 ? kItemLanesNarrow : kItemLanesWide;
+        LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
+        LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
         // The thin kernel is latency-bound (8 lanes per record, gathers from HBM: half of its VALU slots idle) and
         // nothing waits for it: a small grid of it (2 workgroups per CU, grid-stride) is queued BEHIND the item
         // builder, which is on the leaf kernels' critical path, and runs beside the leaf kernels.  (Launched first
         // with 12 workgroups per CU it held the chip while the item builder ran: 14.72 -> 14.50 ms on the whole
         // range, 2.26 -> 2.21 ms on the slowest 8-way shard; scripts/time_enum_variant.py.)
-        int thin_per_cu = 2;
-        if (const char* ev = getenv("LP_ENUM_THIN_PER_CU")) thin_per_cu = std::max(1, atoi(ev));   // (A/B)
+        const int thin_per_cu = 2;
         const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * thin_per_cu);
-        int thin_order = 1;   // 0: thin first (beside the item builder); 1: behind the item builder; 2: behind the leaf kernels
-        if (const char* ev = getenv("LP_ENUM_THIN_ORDER")) thin_order = atoi(ev);   // (A/B)
         auto launch_thin = [&]() {
             if (exact)
                 hipLaunchKernelGGL(k_enum_thin<true>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
             else
                 hipLaunchKernelGGL(k_enum_thin<false>, grid_thin, LEAF_THREADS, 0, sT, p->dev, pd, roots, level, bound, b, e);
         };
-        if (thin_order == 0) launch_thin();
         hipLaunchKernelGGL(k_enum_make_items<true>, lp_ceil_div(bound * lanes, 1024), 1024, 0, s, p->dev, pd,
                            roots, level, bound, THIN_TAIL, lanes, b, e);
-        if (side) {
-            LP_HIP(ctx, hipEventRecord(ctx->aux_event[1], s));          // both item tables are built
-            LP_HIP(ctx, hipStreamWaitEvent(s1, ctx->aux_event[1], 0));
-            if (thin_order >= 1) LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[1], 0));
-        }
-        if (thin_order == 1) launch_thin();
+        LP_HIP(ctx, hipEventRecord(ctx->aux_event[1], s));          // both item tables are built
+        LP_HIP(ctx, hipStreamWaitEvent(s1, ctx->aux_event[1], 0));
+        LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[1], 0));
+        launch_thin();
         // both leaf kernels with resident-sized grids (3 workgroups per CU).  (2 for table 1's kernel gives the best
         // single passes — C(28,14) 1.17 against 1.19 ms, C(32,16) 13.2 against 13.3 — but half of the passes then take
-        // 14.0-14.1 ms: the average is worse.  LP_ENUM_GRID2 / LP_ENUM_GRID1: workgroups per CU, A/B.)
-        int grid2 = grid6, grid1 = grid6;
-        if (const char* ev = getenv("LP_ENUM_GRID2")) grid2 = ctx->num_cus * std::max(1, atoi(ev));   // (A/B: workgroups per CU)
-        if (const char* ev = getenv("LP_ENUM_GRID1")) grid1 = ctx->num_cus * std::max(1, atoi(ev));
+        // 14.0-14.1 ms: the average is worse.)
+        const int grid2 = grid6, grid1 = grid6;
         if (exact) {
             hipLaunchKernelGGL((k_enum_leaves<2, true>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, true>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
@@ -1411,13 +1412,10 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
             hipLaunchKernelGGL((k_enum_leaves<2, false>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, false>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         }
-        if (thin_order >= 2) launch_thin();
-        if (side) {
-            LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));
-            LP_HIP(ctx, hipEventRecord(ctx->aux_event[2], s1));
-            LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[0], 0));
-            LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[2], 0));
-        }
+        LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));
+        LP_HIP(ctx, hipEventRecord(ctx->aux_event[2], s1));
+        LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[0], 0));
+        LP_HIP(ctx, hipStreamWaitEvent(s, ctx->aux_event[2], 0));
     } else {
         hipLaunchKernelGGL(k_enum_make_items<false>, lp_ceil_div(bound, 1024), 1024, 0, ctx->stream, p->dev, pd,
                            roots, level, bound, 0, 1, b, e);

@@ -281,7 +281,7 @@ int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_s
     ++launches;
     int batch = 16, k = 0;
     int status = kRunning;
-    const int dbg = getenv("LP_OVERLAP_DEBUG") ? atoi(getenv("LP_OVERLAP_DEBUG")) : 0;   // 1: selection only (timing)
+    const int dbg = 0;   // (1: selection only — timing experiments of diagnostic builds)
     // Launches turn into no-ops once the state leaves kRunning, so they are queued in growing batches and
     // the status word is polled once per batch.
     for (;;) {

@@ -57,7 +57,6 @@ struct ResidentDev {
     int flags;      // bit 0: write-through stores even when all participants share an XCD (diagnostics)
     char* comm;     // one allocation, zeroed before every launch; carved below (byte offsets)
     unsigned rec_off;            // [2][G] 32-byte records
-    unsigned recA_off, recB_off; // (round-2 kernel)
     unsigned col_off, dpub_off, recS_off, colS_off, census_off, abort_off, comm_bytes;
     unsigned long long* stamps;  // diagnostic: 8 cycle stamps per pivot from workgroup 0 (nullptr = off)
 };
@@ -67,7 +66,6 @@ struct lp_simplex_problem {
     SimplexDev dev{};
     LookDev look{};
     ResidentDev res{};            // res.G == 0: shape outside the chip-resident path
-    bool res_v1 = false;          // A/B only (LP_RESIDENT_V1 at upload): res is planned for the round-2 kernel
     int n_orig = 0;
     size_t tableau_bytes = 0;
     void* arena = nullptr;        // ONE device allocation (from the context's pool) behind every pointer below
@@ -112,9 +110,6 @@ int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_s
 // simplex_resident.hip
 int lp_resident_plan(int m, int n, ResidentDev* out);   // fills G/stride/mpad/offsets; 0 if the shape does not fit
 int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
-// simplex_resident_v1.hip (round-2 kernel, A/B only)
-int lp_resident_plan_v1(int m, int n, ResidentDev* out);
-int lp_simplex_run_resident_v1(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 
 // simplex_lookahead.hip
 int lp_lookahead_pick_j(int m, int n);

@@ -1044,7 +1044,6 @@ int lp_resident_plan(int m, int n, ResidentDev* out) {
 }
 
 int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats) {
-    if (p->res_v1) return lp_simplex_run_resident_v1(p, eps, max_iter, stats);   // (A/B: LP_RESIDENT_V1 at upload)
     lp_context* ctx = p->ctx;
     const SimplexDev& d = p->dev;
     const ResidentDev& rd = p->res;

@@ -80,28 +80,57 @@ public:
         };
         std::vector<Shard> sh((size_t)n_gpus);
         std::vector<lp_comm*> local((size_t)n_gpus, nullptr);
+        auto release = [&]() {
+            for (auto& s : sh) {
+                lp_enum_free(s.p);
+                lp_comm_destroy(s.comm);
+                lp_context_destroy(s.ctx);
+                s.p = nullptr; s.comm = nullptr; s.ctx = nullptr;
+            }
+        };
+        // Set-up, BEFORE anybody can be waiting in a collective: every shard's context (device binding +
+        // stream of its own: shards may share a device) and replica of the problem.  A device that cannot
+        // be opened, or an upload that fails, ends the whole call here — no thread has been started and
+        // nobody has entered ncclCommInitRank, so there is nobody to leave behind.
+        for (int g = 0; g < n_gpus; ++g) {
+            Shard& s = sh[(size_t)g];
+            s.res.x = lpla::VectorXd::Zero(n_orig);
+            s.res.basis.assign((size_t)m, -1);
+            s.rc = lp_context_create(shard_device(g, ndev), nullptr, &s.ctx);
+            if (s.rc == LP_OPTIMAL) s.rc = lp_enum_upload(s.ctx, A.data(), m, n, b.data(), c.data(), maximize, &s.p);
+            if (s.rc != LP_OPTIMAL) {
+                const int rc = s.rc;
+                const std::string why = "shard " + std::to_string(g) + " (device " + std::to_string(shard_device(g, ndev)) +
+                                        "): " + (s.ctx ? lp_last_error(s.ctx) : "lp_context_create failed");
+                release();
+                r.status = rc;
+                if (!throw_on_failure) return r;
+                if (rc == LP_BAD_ARG) throw std::invalid_argument("bad argument: " + why);
+                throw std::runtime_error("sharded enumeration: set-up failed (status " + std::to_string(rc) + "): " + why);
+            }
+        }
         unsigned char id[128] = {0};
         if (rccl) {
-            if (lp_comm_unique_id(id) != LP_OPTIMAL) throw std::runtime_error("simplexmethod_amd: RCCL is not available");
+            if (lp_comm_unique_id(id) != LP_OPTIMAL) {
+                release();
+                throw std::runtime_error("simplexmethod_amd: RCCL is not available");
+            }
         } else if (lp_comm_create_local(n_gpus, local.data()) != LP_OPTIMAL) {
+            release();
             throw std::runtime_error("simplexmethod_amd: lp_comm_create_local failed");
         }
         auto run = [&](int g) {
             Shard& s = sh[(size_t)g];
-            s.res.x = lpla::VectorXd::Zero(n_orig);
-            s.res.basis.assign((size_t)m, -1);
-            // a context (device binding + stream) of its own: shards may share a device
-            s.rc = lp_context_create((_device + g) % ndev, nullptr, &s.ctx);
-            if (s.rc == LP_OPTIMAL) s.rc = lp_enum_upload(s.ctx, A.data(), m, n, b.data(), c.data(), maximize, &s.p);
-            if (rccl) {   // collective: every thread joins, also one whose upload failed
+            if (rccl) {   // collective: every thread joins (every context exists)
                 lp_comm* cm = nullptr;
-                const int crc = s.ctx ? lp_comm_create_rccl(s.ctx, g, n_gpus, id, &cm) : LP_BAD_ARG;
-                if (s.rc == LP_OPTIMAL) s.rc = crc;
+                s.rc = lp_comm_create_rccl(s.ctx, g, n_gpus, id, &cm);
                 s.comm = cm;
             } else {
                 s.comm = local[(size_t)g];
             }
-            if (s.rc == LP_OPTIMAL && g == _debug_fail_shard) s.rc = LP_BAD_ARG;   // (tests)
+#ifdef LP_HOST_TEST_HOOKS
+            if (s.rc == LP_OPTIMAL && g == _debug_fail_shard) s.rc = LP_BAD_ARG;
+#endif
             if (s.rc == LP_OPTIMAL) {
                 uint64_t counts[3] = {0, 0, 0};
                 s.rc = lp_enum_solve_sharded(s.comm, s.p, n_orig, s.res.x.data(), s.res.basis.data(), &s.res.rank,
@@ -112,11 +141,11 @@ public:
             } else {
                 // a shard that cannot enumerate still owes the others its record: they are waiting in
                 // the exchange (a NULL communicator — RCCL set-up failed — has nobody to tell)
-                const std::string why = s.ctx ? lp_last_error(s.ctx) : "";
+                const std::string why = lp_last_error(s.ctx);
                 s.rc = lp_enum_shard_abstain(s.comm, s.rc);
                 s.error = why;
             }
-            if (s.rc != LP_OPTIMAL && s.ctx && s.error.empty()) s.error = lp_last_error(s.ctx);
+            if (s.rc != LP_OPTIMAL && s.error.empty()) s.error = lp_last_error(s.ctx);
             s.res.status = s.rc;
         };
         std::vector<std::thread> th;
@@ -132,11 +161,7 @@ public:
             }
         r = sh[0].res;
         r.status = rc;
-        for (auto& s : sh) {
-            lp_enum_free(s.p);
-            lp_comm_destroy(s.comm);
-            lp_context_destroy(s.ctx);
-        }
+        release();
         if (rc != LP_OPTIMAL && throw_on_failure) {
             if (rc == LP_INFEASIBLE) throw std::runtime_error("No feasible basis");
             if (rc == LP_BAD_ARG) throw std::invalid_argument("bad argument: " + error);
@@ -145,12 +170,25 @@ public:
         return r;
     }
 
-    // Tests only: shard g behaves as if its upload had failed (it must still join the exchange and
-    // every shard must come back with its status).
+#ifdef LP_HOST_TEST_HOOKS
+    // Test builds only (tests/cpp, -DLP_HOST_TEST_HOOKS).  debug_fail_shard: shard g fails after the set-up, as
+    // if its pass had failed (it must still join the exchange and every shard must come back with its status).
+    // debug_shard_device: shard g is bound to HIP device `device` (e.g. one that does not exist).
     void debug_fail_shard(int g) { _debug_fail_shard = g; }
+    void debug_shard_device(int g, int device) { _debug_dev_shard = g; _debug_dev = device; }
+#endif
 
 private:
+    // shard g runs on HIP device (device + g) % device count
+    int shard_device(int g, int ndev) const {
+#ifdef LP_HOST_TEST_HOOKS
+        if (g == _debug_dev_shard) return _debug_dev;
+#endif
+        return (_device + g) % ndev;
+    }
     Canonical _problem;
     int _device;
-    int _debug_fail_shard = -1;
+#ifdef LP_HOST_TEST_HOOKS
+    int _debug_fail_shard = -1, _debug_dev_shard = -1, _debug_dev = 0;
+#endif
 };

@@ -184,6 +184,18 @@ TEST(Enumeration_FailingShardStillJoinsTheExchange) {
         es2.debug_fail_shard(bad);
         CHECK_THROWS(es2.solve_ex(4, true, EnumerationSolver::EXCHANGE_LOCAL), std::invalid_argument);
     }
+    // A shard whose DEVICE cannot be opened ends the whole call during the set-up: no thread has been started,
+    // nobody has entered a collective (with RCCL: ncclCommInitRank), so nobody can be left waiting for it.
+    for (auto ex : {EnumerationSolver::EXCHANGE_LOCAL, EnumerationSolver::EXCHANGE_RCCL}) {
+        const int shards = ex == EnumerationSolver::EXCHANGE_RCCL ? 1 : 3;   // (RCCL needs a device per shard)
+        EnumerationSolver es3(*can);
+        es3.debug_shard_device(shards - 1, 4096);
+        CHECK(es3.solve_ex(shards, false, ex).status == LP_BAD_ARG);
+        EnumerationSolver es4(*can);
+        es4.debug_shard_device(shards - 1, 4096);
+        CHECK_THROWS(es4.solve_ex(shards, true, ex), std::invalid_argument);
+        CHECK(EnumerationSolver(*can).solve_ex(shards, true, ex).status == LP_OPTIMAL);   // and the next call works
+    }
     // the C entry point with no problem takes part as a failed participant too
     lp_comm* comms[2] = {nullptr, nullptr};
     CHECK(lp_comm_create_local(2, comms) == LP_OPTIMAL);

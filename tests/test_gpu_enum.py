@@ -770,6 +770,30 @@ def test_prefix_pivots_outside_fast_reciprocal_range(ctx, m, n, seed, scale):
     p.free()
 
 
+@pytest.mark.parametrize("m,n,seed", [(7, 16, 31), (8, 15, 32), (6, 18, 33)])
+def test_fast_reciprocal_flag_with_singular_subsets(ctx, m, n, seed):
+    """Small-integer data: thousands of subsets are singular by an exactly-zero pivot.  Such a pivot's verdict
+    is final (nothing was divided by anything out of range before it), so the fast leaf kernels must NOT switch
+    to plain divisions on it — and the same data scaled to 2^-510 / 2^505, where the pivots in front of a zero
+    one are out of range too (every later value then rests on the fast reciprocal's unspecified quotients, also
+    the ones that make a subset LOOK singular), must switch whatever the subsets' verdicts are.  Counts,
+    optimum and tie-rule rank equal the oracle's every time."""
+    rng = np.random.default_rng(seed)
+    A = np.hstack([rng.integers(-1, 3, (m, n - m)).astype(float), np.eye(m)])
+    b = rng.integers(0, 4, m).astype(float)
+    c = np.concatenate([rng.integers(-2, 4, n - m).astype(float), np.zeros(m)])
+    total = o.binom(n, m)
+    for scale in (1.0, 2.0 ** -510, 2.0 ** 505):
+        As, bs = A * scale, b * scale
+        st, z, counts = o.enum_range(As, bs, c, True, 0, total)
+        assert counts[2] > 100 and counts[0] > 0
+        p = ctx.enum_problem(As, bs, c, True)
+        assert p.range(0, total, capi.ENUM_PREFIX)[:3] == (st, z, counts)
+        assert p.exact_division == (scale != 1.0)
+        assert p.range(0, total, capi.ENUM_DIRECT)[:3] == (st, z, counts)
+        p.free()
+
+
 @pytest.mark.parametrize("m,n,seed", [(8, 20, 11), (16, 22, 12), (7, 30, 13), (18, 24, 14), (6, 14, 15)])
 def test_prefix_fast_and_plain_division_agree(ctx, m, n, seed, monkeypatch):
     """The default leaf kernels (fast reciprocal) and their plain-division instantiations
