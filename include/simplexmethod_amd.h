@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LP_ABI_VERSION 3 /* 2: lp_simplex_stats grew algo_used / fell_back; lp_enum_shard_abstain, lp_batched_shard_bounds; 3: LP_SIMPLEX_ALGO_OVERLAP, lp_enum_exact_division, lp_debug_reciprocal */
+#define LP_ABI_VERSION 4 /* 2: lp_simplex_stats grew algo_used / fell_back; lp_enum_shard_abstain, lp_batched_shard_bounds; 3: LP_SIMPLEX_ALGO_OVERLAP, lp_enum_exact_division, lp_debug_reciprocal; 4: lp_debug_division */
 
 /* Status codes; the C++ wrappers map them back to the
  * reference's exception types and messages.                                     */
@@ -269,6 +269,10 @@ int lp_enum_exact_division(const lp_enum_problem* p);
 /* Diagnostic (not part of the drop-in surface): the leaf kernels' fast reciprocal and the plain
  * division 1.0 / x[i], both computed on the device, for the parity test of the two.              */
 int lp_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_out, double* plain_out);
+/* Diagnostic (not part of the drop-in surface): the chip-resident simplex's quotient by the pivot element (the
+ * division's own instruction sequence without its range scaling, applied only to operands inside [2^-500, 2^501) or a
+ * zero numerator) and the plain division num[i] / den[i], both computed on the device, for the parity test.      */
+int lp_debug_division(lp_context* ctx, const double* num, const double* den, int n, double* fast_out, double* plain_out);
 
 /* ---- Enumeration sharded over the GPUs of a node (README.md:27,40-42) ------
  * One participant per GPU — a process, or a host thread of one process — each with its own

@@ -5,16 +5,17 @@ ab_libs/, and each is run on 512 x 1024.
   python scripts/resident_marks.py build         (here: hipcc cross-compiles, a few at a time)
   python scripts/resident_marks.py run           (on the GPU box: prints cycles per pivot of every interval)
 
-Marks of the communication wave: 0 loop top (poll starts), 1 all records fresh, 2 decision block written,
-3 after the decision barrier, 4 after the pivot-row barrier, 5 after the ratio barrier, 6 record stored,
-7 after the publication barrier.  Marks of row wave 0: 10 after the decision barrier, 11 decision read,
-12 before / 13 after the pivot-row barrier, 14 priced, 15 eta entry known, 16 before / 17 after the ratio
-barrier, 18 before / 19 after the publication barrier, 20 loop end."""
+Marks of the communication wave: 0 loop top (polling starts), 1 all pricing records fresh, 2 winner decided,
+3 the winner's slice records fresh, 7 after the candidate barrier, 4 decision block written, 5 after the decision barrier.
+Marks of row wave 0: 18 after the candidate barrier, 10 after the decision barrier (candidate row staged), 11 decision
+read, 16 quotients, 12 pivot-row entries read, reduced costs, 13 priced and pricing record stored, 14 entering column
+arrived / eta entry, 15 candidate column and slice record stored, 17 rank-1 update done."""
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PAIRS = [(0, 1), (1, 2), (2, 3), (3, 5), (5, 6), (6, 0), (10, 11), (11, 14), (14, 15), (15, 16), (17, 20), (20, 10)]
+PAIRS = [(0, 1), (1, 2), (2, 3), (3, 7), (7, 4), (4, 5), (5, 0),
+         (18, 10), (10, 11), (11, 16), (16, 12), (12, 13), (13, 14), (14, 15), (15, 17), (17, 18)]
 if os.environ.get("LP_MARK_PAIRS"):   # e.g. LP_MARK_PAIRS=5-30,30-31
     PAIRS = [tuple(int(v) for v in t.split("-")) for t in os.environ["LP_MARK_PAIRS"].split(",")]
 AB = os.path.join(ROOT, "ab_libs")
@@ -42,12 +43,15 @@ def build():
             print("built", lib, flush=True)
 
 
-NAMES = {(0, 1): "comm: poll until all records are fresh (the hop)", (1, 2): "comm: decide, write the decision block",
-         (2, 3): "comm: decision barrier", (3, 5): "comm: waits for the rows (decision read, mirror row, quotients, pricing, ratio slices, ratio barrier)",
-         (5, 6): "comm: ratio stage 2, record out", (6, 0): "comm: loop",
-         (10, 11): "rows: read the decision block", (11, 14): "rows: column request, pivot-row entries from the mirror, two quotients, reduced costs, pricing",
-         (14, 15): "rows: entering column arrived, eta entry", (15, 16): "rows: candidate column, ratio, slice summary",
-         (17, 20): "rows: rank-1 update, mirror write", (20, 10): "rows: wait for the next decision"}
+NAMES = {(0, 1): "comm: poll until all pricing records are fresh", (1, 2): "comm: pricing decision (winner)",
+         (2, 3): "comm: poll the winner's slice records (the hop on the critical path)",
+         (3, 7): "comm: candidate rows to LDS, candidate barrier", (7, 4): "comm: combine the slices, write the decision block",
+         (4, 5): "comm: decision barrier", (5, 0): "comm: trace, loop",
+         (18, 10): "rows: stage my wave's candidate row, decision barrier", (10, 11): "rows: read the decision block, column request",
+         (11, 16): "rows: quotients by the pivot element",
+         (16, 12): "rows: pivot-row entries, reduced costs", (12, 13): "rows: pricing, pricing record out",
+         (13, 14): "rows: entering column arrived, eta entry, xB", (14, 15): "rows: candidate column, ratio, slice record and column out",
+         (15, 17): "rows: rank-1 update", (17, 18): "rows: wait for the candidates"}
 
 
 def run():
@@ -58,7 +62,7 @@ def run():
                    "the workgroups; each interval from its own diagnostic build (two clock reads per pivot)", "intervals": {}}
     code = ("import os,sys; sys.path.insert(0, %r); from simplexmethod_amd import capi; ctx = capi.Context(0); "
             "A,b,c,basis = capi.gen_lp(0,512,1024); p = ctx.simplex_problem(A,b,c,basis,True,512); "
-            "[ (p.reset(), p.run(algo=capi.SIMPLEX_RESIDENT)) for _ in range(3)]; os.environ['LP_RESIDENT_MARKS']='1'; "
+            "[ (p.reset(), p.run(algo=capi.SIMPLEX_RESIDENT)) for _ in range(3)]; "
             "p.reset(); rc, st = p.run(algo=capi.SIMPLEX_RESIDENT); print('solve_ms %%.4f pivots %%d' %% (st.solve_ms, st.pivots))" % ROOT)
     for a, c in PAIRS:
         env = dict(os.environ, LP_LIB_PATH=os.path.join(AB, "libmarks_%d_%d.so" % (a, c)), LP_RESIDENT_STRICT="1")

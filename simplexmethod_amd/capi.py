@@ -83,6 +83,7 @@ SIGNATURES = {
     "lp_enum_free": (None, [_vp]),
     "lp_enum_exact_division": (C.c_int, [_vp]),
     "lp_debug_reciprocal": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "lp_debug_division": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp, _dp]),
     "lp_comm_unique_id": (C.c_int, [_vp]),
     "lp_comm_create_rccl": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "lp_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -229,6 +230,13 @@ class Context:
         x = _f64(x).reshape(-1)
         fast, plain = np.empty_like(x), np.empty_like(x)
         self.check(self.lib.lp_debug_reciprocal(self.h, _d(x), len(x), _d(fast), _d(plain)))
+        return fast, plain
+
+    def debug_division(self, num, den):
+        """(fast, plain): the chip-resident simplex's quotient sequence and num / den, both from the device."""
+        num, den = _f64(num).reshape(-1), _f64(den).reshape(-1)
+        fast, plain = np.empty_like(num), np.empty_like(num)
+        self.check(self.lib.lp_debug_division(self.h, _d(num), _d(den), len(num), _d(fast), _d(plain)))
         return fast, plain
 
     def simplex_solve(self, A, b, c, basis, maximize=True, n_orig=None, eps=EPS,

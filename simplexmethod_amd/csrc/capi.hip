@@ -140,7 +140,6 @@ void lp_simplex_free(lp_simplex_problem* p) {
     (void)hipFree(p->ov_T);
     (void)hipFree(p->ov_vec);
     (void)hipFree(p->look.stamps);
-    (void)hipFree(p->res.stamps);
     if (p->h_state) {   // pinned block + events: kept for the next problem of this context
         lp_context::HostBundle hb;
         hb.pinned = p->h_state;
@@ -609,19 +608,10 @@ int lp_debug_simplex_stamps(lp_simplex_problem* p, int cap_pivots, unsigned long
         const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)(cap_pivots + 64);
         LP_HIP(ctx, hipMalloc(&p->look.stamps, bytes));
         LP_HIP(ctx, hipMemset(p->look.stamps, 0, bytes));
-        const size_t rbytes = sizeof(unsigned long long) * 16 * 256 * 2;   // the resident kernel: 16 per-phase cycle sums per workgroup + 16 progress markers
-        LP_HIP(ctx, hipMalloc(&p->res.stamps, rbytes));
-        LP_HIP(ctx, hipMemset(p->res.stamps, 0, rbytes));
         return LP_OPTIMAL;
     }
-    if (out) {
-        if (p->last_algo == LP_SIMPLEX_ALGO_RESIDENT)
-            LP_HIP(ctx, hipMemcpy(out, p->res.stamps, sizeof(unsigned long long) * 16 * (size_t)(cap_pivots < 256 ? cap_pivots : 256),
-                                  hipMemcpyDeviceToHost));   // cap_pivots = workgroups wanted here
-        else
-            LP_HIP(ctx, hipMemcpy(out, p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)cap_pivots,
-                                  hipMemcpyDeviceToHost));
-    }
+    if (out)
+        LP_HIP(ctx, hipMemcpy(out, p->look.stamps, sizeof(unsigned long long) * 8 * (size_t)cap_pivots, hipMemcpyDeviceToHost));
     return LP_OPTIMAL;
 }
 
@@ -740,6 +730,12 @@ int lp_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fast_ou
     if (!ctx || !x || !fast_out || !plain_out || n <= 0) return LP_BAD_ARG;
     LP_HIP(ctx, hipSetDevice(ctx->device));
     return lp_enum_debug_reciprocal(ctx, x, n, fast_out, plain_out);
+}
+
+int lp_debug_division(lp_context* ctx, const double* num, const double* den, int n, double* fast_out, double* plain_out) {
+    if (!ctx || !num || !den || !fast_out || !plain_out || n <= 0) return LP_BAD_ARG;
+    LP_HIP(ctx, hipSetDevice(ctx->device));
+    return lp_simplex_debug_division(ctx, num, den, n, fast_out, plain_out);
 }
 
 void lp_enum_free(lp_enum_problem* p) {

@@ -476,4 +476,33 @@ __device__ __forceinline__ int block_select_stage2_n(const double* vals, int len
     return wave_chain_select<WANT_MAX, K>(len, eps, best, load);
 }
 
+// ---------------------------------------------------------------------------
+// Quotients by a wave-uniform denominator (round 4: the pivot element u_r divides three times per pivot — 1/u_r,
+// -d_e/u_r, -u_i/u_r — and an fp64 division is ~35 dependent instructions, ~320 cycles of a lone wave's time).
+// The compiler's division is: scale both operands (v_div_scale_f64 x 2), reciprocal of the denominator refined
+// twice, quotient, residual, correction (v_div_fmas_f64), special cases (v_div_fixup_f64).  For operands whose
+// magnitudes lie in [2^-500, 2^501) nothing is scaled and nothing is special: v_div_fmas is then a plain fma and the
+// sequence below IS that sequence, instruction for instruction — the same bits as `num / den`
+// (tests/test_gpu_simplex.py::test_midrange_division_matches_division; enum_leaf.hip's recip_midrange is its
+// num = 1 case).  The refined reciprocal depends on the denominator alone: it is computed once, while the
+// numerators are still on their way.  A zero numerator keeps its quotient num * r2 (a zero of the right sign; the
+// correction step would turn -0 into +0).  Operands outside the range: the caller divides plainly.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double mid_recip2(double den) {
+    const double r0 = __builtin_amdgcn_rcp(den);
+    const double r1 = fma(fma(-den, r0, 1.0), r0, r0);
+    return fma(fma(-den, r1, 1.0), r1, r1);
+}
+__device__ __forceinline__ double mid_div(double num, double den, double r2) {
+    const double q = num * r2;
+    const double e = fma(-den, q, num);
+    const double q2 = fma(e, r2, q);
+    return (num == 0.0) ? q : q2;
+}
+__device__ __forceinline__ bool mid_range(double v) {   // 2^-500 <= |v| < 2^501 (not zero, denormal, inf, NaN)
+    const unsigned ex = ((unsigned)__double2hiint(v) >> 20) & 0x7FFu;
+    return ex - 523u <= 1000u;
+}
+__device__ __forceinline__ bool mid_range_or_zero(double v) { return v == 0.0 || mid_range(v); }
+
 }  // namespace lpdev

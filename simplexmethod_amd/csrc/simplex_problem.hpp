@@ -46,19 +46,20 @@ struct LookDev {
 };
 
 // Chip-resident solve (simplex_resident.hip): the tableau lives in the registers of G co-resident
-// workgroups (RS_CPT columns each) for the whole solve; per pivot they exchange one 64-byte record
-// and one entering column each through these buffers (8-byte {epoch tag, value} granules).
+// workgroups (cpt columns each) for the whole solve; per pivot they exchange one 16-byte pricing record, 8-15
+// slice records of the ratio test and one candidate column each through these buffers (8-byte {epoch tag, value}
+// granules).
 struct ResidentDev {
     int G;          // participating workgroups = ceil(n / columns per workgroup)
     int stride;     // participants are the blocks b with b % stride == 0 (8: one XCD under round-robin dispatch)
-    int mpad;       // threads per workgroup = m rounded up to 64 (one tableau row per thread)
-    int pad0;       // (round-2 kernel: flags)
-    int cpt;        // tableau columns per workgroup: 32 (m <= 512) or 16 (m <= 1024)
-    int flags;      // bit 0: write-through stores even when all participants share an XCD (diagnostics)
+    int mpad;       // row threads per workgroup = m rounded up to 64 (one tableau row per thread)
+    int cpt;        // tableau columns per workgroup: 32 (m <= 512) or 16 (m <= 960)
+    int flags;      // bit 0: write-through stores even when all participants share an XCD; bit 1: injected failure (tests)
     char* comm;     // one allocation, zeroed before every launch; carved below (byte offsets)
-    unsigned rec_off;            // [2][G] 32-byte records
-    unsigned col_off, dpub_off, recS_off, colS_off, census_off, abort_off, comm_bytes;
-    unsigned long long* stamps;  // diagnostic: 8 cycle stamps per pivot from workgroup 0 (nullptr = off)
+    unsigned prec_off;           // [2][G] pricing records (16 bytes)
+    unsigned srec_off;           // [2][G][2][16] slice records of the ratio test (A granules, B granules)
+    unsigned col_off;            // [3][G][mpad] candidate columns
+    unsigned dpub_off, recS_off, colS_off, census_off, abort_off, comm_bytes;
 };
 
 struct lp_simplex_problem {
@@ -110,6 +111,7 @@ int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_s
 // simplex_resident.hip
 int lp_resident_plan(int m, int n, ResidentDev* out);   // fills G/stride/mpad/offsets; 0 if the shape does not fit
 int lp_simplex_run_resident(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
+int lp_simplex_debug_division(lp_context* ctx, const double* num, const double* den, int n, double* fast_out, double* plain_out);
 
 // simplex_lookahead.hip
 int lp_lookahead_pick_j(int m, int n);

@@ -32,7 +32,7 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_strings():
     lib = capi.load()
-    assert lib.lp_abi_version() == 3
+    assert lib.lp_abi_version() == 4
     assert lib.lp_status_string(0) == b"optimal"
     assert lib.lp_status_string(3) == b"singular basis matrix"
     assert lib.lp_binom(32, 16) == 601080390 and lib.lp_binom(28, 14) == 40116600

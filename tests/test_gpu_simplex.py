@@ -83,11 +83,10 @@ def test_baseline_config_512x1024(ctx, algo):
     np.testing.assert_allclose(A @ xfull, b, rtol=1e-9)
 
 
-@pytest.mark.parametrize("mode", ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_PUBL"])
+@pytest.mark.parametrize("mode", ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1"])
 def test_baseline_config_512x1024_resident_modes(ctx, monkeypatch, mode):
     """The chip-resident kernel's placement-dependent forms, forced: participants spread over all
-    XCDs (write-through stores, no shared L2), write-through stores on one XCD, and the A/B form that
-    publishes the eta column instead of the candidate column itself.  Same bits as the oracle."""
+    XCDs (write-through stores, no shared L2) and write-through stores on one XCD.  Same bits as the oracle."""
     monkeypatch.setenv(mode, "1")
     m, n = 512, 1024
     A, b, c, basis = lpcases.random_lp(0, m, n)
@@ -108,6 +107,21 @@ def test_resident_rows_beyond_512(ctx, seed, m, n):
         g = _run(ctx, A, b, c, basis, True, n - m, algo=algo)
         assert g["algo_used"] == capi.SIMPLEX_RESIDENT
         _assert_bit_exact(g, r)
+
+
+@pytest.mark.parametrize("seed,m,n", [(0, 512, 1024), (43, 960, 1920), (6, 100, 1500)])
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 30, 31])
+def test_resident_iteration_limit_bit_exact(ctx, seed, m, n, max_iter):
+    """The pivot that reaches the iteration limit is applied and nothing is chosen behind it
+    (SimplexSolover.h:450): on that last pivot the kernel publishes no candidate, and the rank-1 update still
+    has to wait, behind the row barrier, until every wave has read the pivot row.  Tableau, reduced costs, xB,
+    basis and trace bit-exact at both register layouts (32 and 16 columns per workgroup) and on a wide shape
+    (47 workgroups)."""
+    A, b, c, basis = lpcases.random_lp(seed, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=64, want_tableau=True, max_iter=max_iter)
+    assert r["status"] == o.ITER_LIMIT and r["iters"] == max_iter
+    g = _run(ctx, A, b, c, basis, True, n - m, trace_cap=64, max_iter=max_iter, algo=capi.SIMPLEX_RESIDENT)
+    _assert_bit_exact(g, r)
 
 
 def test_resident_shape_limit(ctx):
@@ -330,6 +344,41 @@ def test_resident_solves_under_contention(ctx):
             assert np.array_equal(d["basis"], r["basis"]) and np.array_equal(d["x"], r["x"]) and d["obj"] == r["obj"]
             k = r["iters"]
             assert list(zip(d["trace_enter"][:k].tolist(), d["trace_leave"][:k].tolist())) == r["trace"][:k]
+
+
+def test_midrange_division_matches_division(ctx):
+    """The chip-resident kernel's quotients by the pivot element (lpdev::mid_div: the division's own instruction
+    sequence without the range scaling, the reciprocal refined once per denominator) against the device's plain
+    division, which is IEEE's: 4 M operand pairs — random mantissas and exponents over the whole range the fast
+    sequence is applied to, edge mantissas, quotients of equal operands, signed zero numerators, and operands
+    outside the range (where the kernel's rule takes the plain division)."""
+    rng = np.random.default_rng(2027)
+    n = 1 << 22
+
+    def operands(lo, hi):
+        mant = rng.integers(0, 1 << 52, size=n, dtype=np.uint64)
+        edge = np.array([0, 1, 2, 3, (1 << 52) - 1, (1 << 52) - 2, 1 << 51, (1 << 51) + 1, (1 << 51) - 1,
+                         0x5555555555555, 0xAAAAAAAAAAAAA, 0x6A09E667F3BCD, 0x6A09E667F3BCC], dtype=np.uint64)
+        mant[: 64 * len(edge)] = np.tile(edge, 64)
+        expo = rng.integers(lo, hi + 1, size=n).astype(np.int64)
+        v = ((expo + 1023).astype(np.uint64) << np.uint64(52) | mant).view(np.float64).copy()
+        v[rng.random(n) < 0.5] *= -1.0
+        return v
+    num, den = operands(-500, 500), operands(-500, 500)
+    rng.shuffle(den)
+    num[:4096:2] = den[:4096:2]                 # equal operands: the quotient is exactly 1
+    num[4096:8192:4] = 0.0                      # zero numerators of both signs
+    num[4097:8192:4] = -0.0
+    num[8192:9216] = operands(-1022, 1023)[:1024]     # outside the range: the plain division answers
+    den[9216:10240] = operands(-1022, 1023)[:1024]
+    num[10240:10250] = [np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1.7e308, 2.0 ** 501, 2.0 ** -501, 2.0 ** 500, 2.0 ** -500]
+    fast, plain = ctx.debug_division(num, den)
+    with np.errstate(all="ignore"):
+        host = num / den
+    same = (plain.view(np.uint64) == host.view(np.uint64)) | (np.isnan(plain) & np.isnan(host))
+    assert same.all()                                 # the device's division is IEEE's
+    bad = np.flatnonzero((fast.view(np.uint64) != plain.view(np.uint64)) & ~(np.isnan(fast) & np.isnan(plain)))
+    assert bad.size == 0, (num[bad[:4]], den[bad[:4]], fast[bad[:4]], plain[bad[:4]])
 
 
 def test_update_microbenchmarks_and_profiling(ctx):
