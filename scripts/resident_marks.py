@@ -6,16 +6,16 @@ ab_libs/, and each is run on 512 x 1024.
   python scripts/resident_marks.py run           (on the GPU box: prints cycles per pivot of every interval)
 
 Marks of the communication wave: 0 loop top (polling starts), 1 all pricing records fresh, 2 winner decided,
-3 the winner's slice records fresh, 7 after the candidate barrier, 4 decision block written, 5 after the decision barrier.
-Marks of row wave 0: 18 after the candidate barrier, 10 after the decision barrier (candidate row staged), 11 decision
-read, 16 quotients, 12 pivot-row entries read, reduced costs, 13 priced and pricing record stored, 14 entering column
-arrived / eta entry, 15 candidate column and slice record stored, 17 rank-1 update done."""
+3 the winner's slice records fresh, 4 decision block written, 5 after the decision barrier.
+Marks of row wave 0: 10 after the decision barrier, 11 decision read and pivot-row read issued, 16 quotients,
+12 reduced costs, 13 priced and pricing record stored, 14 entering column arrived / eta entry, 15 candidate column
+and slice record stored, 17 rank-1 update and mirror write done."""
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PAIRS = [(0, 1), (1, 2), (2, 3), (3, 7), (7, 4), (4, 5), (5, 0),
-         (18, 10), (10, 11), (11, 16), (16, 12), (12, 13), (13, 14), (14, 15), (15, 17), (17, 18)]
+PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0),
+         (10, 11), (11, 16), (16, 12), (12, 13), (13, 14), (14, 15), (15, 17), (17, 10)]
 if os.environ.get("LP_MARK_PAIRS"):   # e.g. LP_MARK_PAIRS=5-30,30-31
     PAIRS = [tuple(int(v) for v in t.split("-")) for t in os.environ["LP_MARK_PAIRS"].split(",")]
 AB = os.path.join(ROOT, "ab_libs")
@@ -45,13 +45,11 @@ def build():
 
 NAMES = {(0, 1): "comm: poll until all pricing records are fresh", (1, 2): "comm: pricing decision (winner)",
          (2, 3): "comm: poll the winner's slice records (the hop on the critical path)",
-         (3, 7): "comm: candidate rows to LDS, candidate barrier", (7, 4): "comm: combine the slices, write the decision block",
-         (4, 5): "comm: decision barrier", (5, 0): "comm: trace, loop",
-         (18, 10): "rows: stage my wave's candidate row, decision barrier", (10, 11): "rows: read the decision block, column request",
-         (11, 16): "rows: quotients by the pivot element",
-         (16, 12): "rows: pivot-row entries, reduced costs", (12, 13): "rows: pricing, pricing record out",
+         (3, 4): "comm: combine the slices, write the decision block", (4, 5): "comm: decision barrier", (5, 0): "comm: basis, trace, loop",
+         (10, 11): "rows: read the decision block, column request, pivot-row read issued", (11, 16): "rows: quotients by the pivot element",
+         (16, 12): "rows: pivot-row entries arrived, reduced costs", (12, 13): "rows: pricing, pricing record out",
          (13, 14): "rows: entering column arrived, eta entry, xB", (14, 15): "rows: candidate column, ratio, slice record and column out",
-         (15, 17): "rows: rank-1 update", (17, 18): "rows: wait for the candidates"}
+         (15, 17): "rows: rank-1 update, mirror write", (17, 10): "rows: wait for the next decision"}
 
 
 def run():

@@ -70,12 +70,16 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 enum { MODE_PIVOT = 0, MODE_OPTIMAL = 1, MODE_UNBOUNDED = 2, MODE_SLOW = 3, MODE_FAIL = 4, MODE_RSLOW = 5 };
 
-struct Ctl {   // decision of the current pivot, written by the communication wave, read by everyone after a barrier
-    int mode_kst, e, r, slot;   // mode | winner's workgroup << 8; entering column; leaving row; where its staged copy is
+struct CtlHead {   // decision of one pivot, written by the communication wave, read by everyone after a barrier
+    int mode_kst, e, r, pad0;   // mode | winner's workgroup << 8; entering column; leaving row
     double ur, dE;              // pivot element; scan value of the entering column (maximise: d_e, minimise: -d_e)
+};
+struct Ctl {
+    CtlHead h[2];   // by the parity of the pivot's epoch: the next decision is written while a slow wave may still be
+                    // reading this one (ONE barrier per pivot; a wave cannot be two decisions behind)
     int fail, plain, stale, pad;
 };
-static_assert(sizeof(Ctl) == 48, "Ctl's head is read as two 16-byte LDS loads");
+static_assert(sizeof(CtlHead) == 32 && sizeof(Ctl) == 80, "a head is read as two 16-byte LDS loads");
 
 // ---- granules -------------------------------------------------------------------------------
 // column granules: full 32-bit epoch tags
@@ -137,13 +141,12 @@ struct Spin {
 };
 
 struct Shared {
-    double* slots;   // RS_SLICES x (CPT + 2): candidate pivot rows — slice w's first-minimum row of the winner's column,
-                     // staged by its owner (a thread of row wave w) while the communication wave still combines the slices
-    int* cand;       // RS_SLICES : those rows (-1: none), from the winner's slice records
+    double* prow;    // CPT + 8   : !MIRROR: this workgroup's part of the pivot row (+ xB_r at CPT), staged by thread r
+    double* mirror;  // NT x (CPT + 2): MIRROR: row-readable copy of the register slab (+ xB), see RS_MIRROR_WRITE
+    unsigned* readers;   // 1: row waves that have read the pivot row of the mirror, summed over the solve
     double* ratio;   // NT        : ratio-test values of the entering column (near-tie replays only)
     double* u;       // NT        : that column
     Ctl* ctl;
-    int* basis;      // NT        : N by position (every workgroup keeps its own copy; the communication wave's)
     SimplexDev* stash;   // the kernel's arguments for the epilogue: re-read from here, the pivot loop is ~100 SGPRs
                          // short and every uniform value kept live across it is reloaded by v_readlane chains
 };
@@ -164,15 +167,15 @@ __device__ __forceinline__ T lds_reload(const T* p) {
 // sized for the instantiation's largest row count NT: the workgroup has the CU to itself anyway), so that every
 // LDS address in the pivot loop is an immediate and none of the base pointers occupies an SGPR
 __host__ __device__ constexpr size_t resident_lds_bytes(int nt, int cpt) {
-    return sizeof(double) * (16 * ((size_t)cpt + 2) + 2 * (size_t)nt) + 64 /* cand */ + sizeof(Ctl) + 16 +
-           sizeof(int) * (size_t)nt + 256 /* stash */;
+    return sizeof(double) * ((size_t)cpt + 8 + 2 * (size_t)nt) + sizeof(Ctl) + 16 + 256 /* stash */ +
+           (nt > 512 ? sizeof(double) * (size_t)nt * ((size_t)cpt + 2) : 0) /* mirror */;
 }
 
 struct Decision {   // the decision block as the row waves use it
-    int mode, kst, e, r, slot;
+    int mode, kst, e, r;
     double ur, dE;   // (per-lane copies of wave-uniform values: they feed vector arithmetic only)
 };
-__device__ __forceinline__ Decision ctl_read(const Ctl* p) {
+__device__ __forceinline__ Decision ctl_read(const CtlHead* p) {
     const v4i a = *reinterpret_cast<const v4i*>(p);
     const v2d b = *reinterpret_cast<const v2d*>(&p->ur);
     Decision o;
@@ -181,7 +184,6 @@ __device__ __forceinline__ Decision ctl_read(const Ctl* p) {
     o.kst = mk >> 8;
     o.e = __builtin_amdgcn_readfirstlane(a.y);
     o.r = __builtin_amdgcn_readfirstlane(a.z);
-    o.slot = __builtin_amdgcn_readfirstlane(a.w);
     o.ur = b[0];
     o.dE = b[1];
     return o;
@@ -215,6 +217,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     constexpr int NWMAX = NT <= 512 ? 8 : 16;   // slices of the ratio test (a power of two >= row waves)
     static_assert(NWMAX <= RS_SLICES, "slice records of a workgroup");
     constexpr int KREPLAY = 4;                  // entries per lane and tile of the near-tie replay (256-row tiles)
+    // How the pivot row reaches the waves (measured, round 4): with 8 row waves its owner stages it behind a second
+    // barrier (2.45 us per pivot at 512 x 1024 against 2.74 with the mirror, whose 139 KB of LDS stores per pivot
+    // compete with the communication wave for the time the slice records travel); with up to 15 row waves that
+    // barrier costs more than the mirror (768 x 1536: 4.16 against 3.78 us).
+    constexpr bool MIRROR = NT > 512;
     typedef double vslab __attribute__((ext_vector_type(HALF)));
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (blockIdx.x % (unsigned)rd.stride) return;
@@ -240,16 +247,19 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     constexpr unsigned long long kPosInf = 0xFFF0000000000000ull;   // f64_sort_key(+inf)
 
     Shared sh;
-    constexpr int SS = CPT + 2;   // doubles per staged row (CPT entries, xB_r, padding to 16 bytes)
-    sh.slots = smem;
-    sh.ratio = sh.slots + RS_SLICES * SS;
+    sh.prow = smem;
+    sh.ratio = sh.prow + CPT + 8;
     sh.u = sh.ratio + NT;
-    sh.cand = reinterpret_cast<int*>(sh.u + NT);
-    sh.ctl = reinterpret_cast<Ctl*>(sh.cand + 16);
-    sh.basis = reinterpret_cast<int*>(reinterpret_cast<char*>(sh.ctl) + sizeof(Ctl) + 16);
-    sh.stash = reinterpret_cast<SimplexDev*>(sh.basis + NT);
+    sh.ctl = reinterpret_cast<Ctl*>(sh.u + NT);
+    sh.readers = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sh.ctl) + sizeof(Ctl));
+    sh.stash = reinterpret_cast<SimplexDev*>(reinterpret_cast<char*>(sh.ctl) + sizeof(Ctl) + 16);
     static_assert(sizeof(SimplexDev) <= 256, "resident_lds_bytes reserves 256 bytes for the stash");
-    if (tid == 0) *sh.stash = d;
+    if (tid == 0) {
+        *sh.stash = d;
+        *sh.readers = 0u;
+    }
+    sh.mirror = reinterpret_cast<double*>(reinterpret_cast<char*>(sh.stash) + 256);
+    constexpr int MS = CPT + 2;   // row stride of the mirror in doubles (16-byte rows; 272 / 144 bytes: b128 stores conflict-free)
 
     Comm cm;
     cm.r = __builtin_amdgcn_make_buffer_rsrc(rd.comm, 0, rd.comm_bytes, 0x00020000);
@@ -273,16 +283,21 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             asm volatile("" : "+v"(dst));            \
         }                                            \
     } while (0)
-    // This thread's row (CPT entries + xB) into staging slot S: 16-byte stores of one lane
-#define RS_STAGE_ROW(S)                                                             \
-    do {                                                                            \
-        double* sr_ = sh.slots + (S) * SS;                                          \
-        _Pragma("unroll") for (int j = 0; j < HALF; j += 2) {                        \
-            const v2d a_ = {Ta[j], Ta[j + 1]}, b_ = {Tb[j], Tb[j + 1]};             \
-            *reinterpret_cast<v2d*>(sr_ + j) = a_;                                  \
-            *reinterpret_cast<v2d*>(sr_ + HALF + j) = b_;                           \
-        }                                                                           \
-        sr_[CPT] = xb;                                                              \
+    // The LDS mirror: every row thread keeps a copy of its row (CPT entries + xB) where the OTHER waves can read
+    // it.  After a decision every wave takes its pivot-row entries straight from row r of the mirror — no staging
+    // by the row's owner, no barrier in front of the pricing.  Written behind the rank-1 update, i.e. while the
+    // slice records travel (139 KB of LDS stores per pivot: they have that time and no more).  Thread r may
+    // overwrite row r only when every row wave has read it: a count of readers in LDS, which the wave owning r
+    // looks at once — it has long been complete — before its stores.
+#define RS_MIRROR_WRITE()                                                                  \
+    do {                                                                                   \
+        double* mr_ = sh.mirror + (size_t)tid * MS;                                        \
+        _Pragma("unroll") for (int j = 0; j < HALF; j += 2) {                               \
+            const v2d a_ = {Ta[j], Ta[j + 1]}, b_ = {Tb[j], Tb[j + 1]};                    \
+            *reinterpret_cast<v2d*>(mr_ + j) = a_;                                         \
+            *reinterpret_cast<v2d*>(mr_ + HALF + j) = b_;                                  \
+        }                                                                                  \
+        mr_[CPT] = xb;                                                                     \
     } while (0)
     {
         const double* Trow = d.T + (size_t)(rowok ? tid : 0) * ld;
@@ -293,13 +308,32 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
     }
     double xb = rowok ? d.T[(size_t)tid * ld + n] : 0.0;   // replica of column n
+    if (MIRROR && !is_comm) RS_MIRROR_WRITE();   // (visible to the other waves behind the census barrier)
     // reduced costs of this workgroup's columns: lane l of EVERY row wave holds column col0 + l
     const int mycol = col0 + lane;
     const bool colok = lane < CPT && mycol < n;
     bool nbl = colok && d.nonbasic[colok ? mycol : 0] != 0;
+    // "my column is basic" (a column may be neither: barred from entering, lp_simplex_phase2_costs).  The column that
+    // LEAVES the basis at a pivot needs no look-up of N(r): a basic column is an exact unit vector — set, not computed
+    // (below and simplex_launch.hip) — so it is the one basic column whose pivot-row entry is 1.
+    if (tid == 0) sh.ctl->pad = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += (int)blockDim.x) {
+        const int bi = d.basis[i] - col0;
+        if (bi >= 0 && bi < CPT) atomicOr(reinterpret_cast<unsigned*>(&sh.ctl->pad), 1u << bi);
+    }
     double dl = colok ? d.T[(size_t)m * ld + mycol] : 0.0;
     double obj = d.T[(size_t)m * ld + n];
-    for (int i = tid; i < m; i += mpad + 64) sh.basis[i] = d.basis[i];
+    // N by position: the communication wave's REGISTERS (lane l, element q: position 64 q + l; every workgroup
+    // keeps its own copy), rewritten with a wave-uniform element index behind the decision — off the pivot's path:
+    // nobody needs the leaving ENTRY (see basl below)
+    constexpr int NBAS = NT / 64 <= 8 ? 8 : 16;
+    typedef int vbas __attribute__((ext_vector_type(NBAS)));
+    vbas basv = 0;
+    if (is_comm) {
+#pragma unroll
+        for (int q = 0; q < NBAS; ++q) basv[q] = (q * 64 + lane < m) ? d.basis[q * 64 + lane] : -1;
+    }
     int it = st->iters;
     int status = (it >= max_iter) ? LP_ITER_LIMIT : kRunning;   // SimplexSolver.h:429,:450
 
@@ -338,6 +372,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
     }
     __syncthreads();
+    bool basl = colok && ((reinterpret_cast<const unsigned*>(&sh.ctl->pad)[0] >> (lane & 31)) & 1u) != 0;
     const bool plain = sh.ctl->plain != 0;
     if (sh.ctl->fail) status = kResidentFailed;
 
@@ -431,13 +466,12 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
     // ======================================================================================================
     if (status == kRunning) RS_NEXT_EPOCH();
     if (is_comm) {
-        int mode = MODE_FAIL, kst = 0, e = -1, r = -1, slot = 0, e_prev = -1, r_prev = -1;
+        int mode = MODE_FAIL, kst = 0, e = -1, r = -1;
         double ur = 0.0, M = 0.0;
         unsigned long long Mk;
-        bool have_prev = false;
         while (status == kRunning) {
             bool failed = false;
-            kst = 0; e = -1; r = -1; ur = 0.0; slot = 0;
+            kst = 0; e = -1; r = -1; ur = 0.0;
             RS_MARK_C(0);
             // (a row thread whose entering column never came says so before it gets to the decision barrier; one that
             // says so after this read is heard at the next pivot — nothing is written back either way)
@@ -566,12 +600,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 const bool isA = lane < 32 && slive;
                 const unsigned long long Ml = isA ? g_u64(b) : kPosInf;
                 const int Jl = isA ? (int)((unsigned)b.x & 0xFFFFu) - 1 : -1;
-                // ---- the candidates for the pivot row — slice w's first minimum is a row of row wave w — go to the
-                // rows at once: their owners stage them while the slices are still being combined here
-                if (lane < RS_SLICES) sh.cand[lane] = failed ? -1 : Jl;
-                lds_barrier();   // ---- the candidate barrier
-                RS_MARK_C(7);
-                if (have_prev && lane == 0) sh.basis[r_prev] = e_prev;   // N(leave_pos) = enter, :196 (every row wave has read the old entry)
                 const int okl = (int)((unsigned)b.z & 0xFFFFu);
                 const double Ul = g_f64(b);
                 const double Mv = lpdev::f64_from_key(Ml);   // this slice's smallest (approximate) ratio, +inf: none
@@ -592,19 +620,13 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     const unsigned long long near2 = __ballot(lane < W2 && !(Mhi < vlow));
                     r = __builtin_amdgcn_readlane(Jl, W2);
                     ur = lpdev::wave_bcast_f64(Ul, W2 + 32);
-                    slot = W2;
                     if (!(okW && near2 == 0ULL)) mode = MODE_RSLOW;   // near-tie: every workgroup replays the chain exactly
                 }
-            } else {
-                if (lane < RS_SLICES) sh.cand[lane] = -1;
-                lds_barrier();   // ---- the candidate barrier
-                RS_MARK_C(7);
-                if (have_prev && lane == 0) sh.basis[r_prev] = e_prev;
             }
             if (fail_seen) mode = MODE_FAIL;
             if (lane == 0) {
-                Ctl* c = sh.ctl;
-                const v4i head = {mode | (kst << 8), e, r, slot};
+                CtlHead* c = &sh.ctl->h[par];
+                const v4i head = {mode | (kst << 8), e, r, 0};
                 *reinterpret_cast<v4i*>(c) = head;
                 c->ur = ur; c->dE = M;
             }
@@ -623,8 +645,8 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 r = lpdev::wave_chain_select<false, KREPLAY>(m, eps, best2, load2);
                 mode = sh.ctl->fail ? MODE_FAIL : (r < 0 ? MODE_UNBOUNDED : MODE_PIVOT);
                 if (lane == 0) {
-                    Ctl* c = sh.ctl;
-                    const v4i head = {mode | (kst << 8), e, r, 0};   // (slot 0: staged behind the slow path)
+                    CtlHead* c = &sh.ctl->h[par];
+                    const v4i head = {mode | (kst << 8), e, r, 0};
                     *reinterpret_cast<v4i*>(c) = head;
                     c->ur = mode == MODE_PIVOT ? sh.u[r] : 0.0;
                 }
@@ -655,11 +677,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 M = best;
                 mode = failed ? MODE_FAIL : ((e < 0 || !(best > eps)) ? MODE_OPTIMAL : MODE_SLOW);
                 if (lane == 0) {
-                    Ctl* c = sh.ctl;
+                    CtlHead* c = &sh.ctl->h[par];
                     const v4i head = {mode | (kst << 8), e, -1, 0};
                     *reinterpret_cast<v4i*>(c) = head;
                     c->dE = best;
-                    if (failed) c->fail = 3;   // code 3: slow-path reduced costs
+                    if (failed) sh.ctl->fail = 3;   // code 3: slow-path reduced costs
                 }
                 lds_barrier();   // S1
                 if (mode == MODE_SLOW) {
@@ -671,7 +693,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                             return sh.ratio[j];
                         };
                         const int r2 = lpdev::wave_chain_select<false, KREPLAY>(m, eps, best2, load2);
-                        if (lane == 0) sh.ctl->r = r2;
+                        if (lane == 0) sh.ctl->h[par].r = r2;
                         lds_barrier();   // O2: thread r2 publishes {r2, u_r2}
                     }
                     Spin spin;
@@ -687,11 +709,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                     r = (int)((unsigned)a.x & 0xFFFFu) - 1;
                     mode = failed ? MODE_FAIL : (r < 0 ? MODE_UNBOUNDED : MODE_PIVOT);
                     if (lane == 0) {
-                        Ctl* c = sh.ctl;
-                        const v4i head = {mode | (kst << 8), e, r, 0};   // (slot 0: staged behind the slow path)
+                        CtlHead* c = &sh.ctl->h[par];
+                        const v4i head = {mode | (kst << 8), e, r, 0};
                         *reinterpret_cast<v4i*>(c) = head;
                         c->ur = g_f64(a);
-                        if (failed) c->fail = 4;   // code 4: slow-path second hop
+                        if (failed) sh.ctl->fail = 4;   // code 4: slow-path second hop
                     }
                     lds_barrier();   // S3
                 }
@@ -700,13 +722,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 status = mode == MODE_OPTIMAL ? LP_OPTIMAL : mode == MODE_UNBOUNDED ? LP_UNBOUNDED : kResidentFailed;
                 break;
             }
-            lds_barrier();   // Z: thread r has staged the pivot row the slow path arrived at (slot 0)
             }
             ++it;
             RS_NEXT_EPOCH();
-            have_prev = true;
-            e_prev = e;
-            r_prev = r;
+            if (!MIRROR) lds_barrier();   // ---- the pivot-row barrier (the rows' business)
+            if (lane == (r & 63)) basv[(r >> 6) & (NBAS - 1)] = e;   // N(leave_pos) = enter, :196
             if (k == 0 && lane == 0) {   // (workgroup 0 only: the trace pointers come from the stash — three LDS reads behind
                                          // the barrier's memory clobber — not from SGPRs held all along)
                 const SimplexDev* sd = sh.stash;
@@ -717,7 +737,6 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             }
             if (it >= max_iter) status = LP_ITER_LIMIT;   // :450: that pivot is applied, no further one is chosen
         }
-        if (have_prev && lane == 0) sh.basis[r_prev] = e_prev;   // (the last pivot's; the epilogue's barrier follows)
         // (this wave owns no rows: fresh values, so that the registers its copy of the slab occupied are not kept
         // alive — idle — through the row waves' loop for the sake of the common epilogue)
         Ta = 0.0;
@@ -732,15 +751,9 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
         while (status == kRunning) {
             RS_MARK_R(20);
-            lds_barrier();   // ---- the candidate barrier: sh.cand[w] = slice w's candidate for the pivot row, one of MY WAVE's rows
-            RS_MARK_R(18);
-            {
-                const int cj = __builtin_amdgcn_readfirstlane(sh.cand[wave]);
-                if (tid == cj) RS_STAGE_ROW(wave);   // (17 stores of one lane; -1: nobody)
-            }
             lds_barrier();   // ---- the decision barrier
             RS_MARK_R(10);
-            Decision cc = ctl_read(sh.ctl);
+            Decision cc = ctl_read(&sh.ctl->h[par]);
             bool have_col = false;
             v4i gcol = {0, 0, 0, 0};
             const unsigned ep_col = ep;
@@ -771,7 +784,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 sh.u[tid] = u_;
                 lds_barrier();   // R1
                 lds_barrier();   // R2
-                cc = ctl_read(sh.ctl);
+                cc = ctl_read(&sh.ctl->h[par]);
             }
             if (cc.mode == MODE_SLOW) {
                 // ---- near-tie in the pricing: every workgroup reaches this branch for the same pivot; only now are all
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 if (wave == 0 && lane < CPT)
                     st16(g_pack(ep, pv), cm.r, cm.dpub + ((par * (unsigned)G + (unsigned)k) * CPT + (unsigned)lane) * 16u, plain);
                 lds_barrier();   // S1
-                cc = ctl_read(sh.ctl);
+                cc = ctl_read(&sh.ctl->h[par]);
                 if (cc.mode == MODE_SLOW) {
                     if (cc.kst == k) {   // second hop: the owner stages the true entering column
                         const int je = __builtin_amdgcn_readfirstlane(cc.e - col0);
@@ -790,13 +803,13 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                         sh.ratio[tid] = (rowok && up > eps) ? nan_to(xb / up, INFINITY) : INFINITY;
                         lds_barrier();   // O1
                         lds_barrier();   // O2
-                        const int r2 = sh.ctl->r;
+                        const int r2 = sh.ctl->h[par].r;
                         if (tid == (r2 >= 0 ? r2 : 0))
                             st16(r_pack(ep, (unsigned)(r2 + 1), 0u, (unsigned long long)__double_as_longlong(r2 >= 0 ? up : 0.0)), cm.r,
                                  cm.recS + par * 16u, plain);
                     }
                     lds_barrier();   // S3
-                    cc = ctl_read(sh.ctl);
+                    cc = ctl_read(&sh.ctl->h[par]);
                     coff = cm.colS + par * col_stride + (unsigned)tid * 16u;
                     if (cc.mode == MODE_PIVOT && cc.kst != k && rowok) gcol = ld16(cm.r, coff);
                 }
@@ -805,11 +818,23 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 status = cc.mode == MODE_OPTIMAL ? LP_OPTIMAL : cc.mode == MODE_UNBOUNDED ? LP_UNBOUNDED : kResidentFailed;
                 break;
             }
-            if (tid == cc.r) RS_STAGE_ROW(0);   // the pivot row the slow path arrived at
-            lds_barrier();   // Z
             }
             const int kst = cc.kst, e = cc.e, r = cc.r;
-            const int oldb = sh.basis[r];   // the basis entry leaving (:196; the communication wave rewrites it behind the pivot-row barrier)
+            // ---- the pivot row, lane j its entry j (lane CPT: xB_r); the quotients by u_r are computed meanwhile.
+            //   MIRROR: ONE LDS read per wave, straight from row r of the mirror (no barrier);
+            //   else  : thread r stages its registers — 17 stores of one lane — behind a second barrier.
+            double pl = 0.0;
+            if (MIRROR) {
+                pl = sh.mirror[(size_t)r * MS + (lane <= CPT ? lane : 0)];
+            } else if (tid == r) {
+#pragma unroll
+                for (int j = 0; j < HALF; j += 2) {
+                    const v2d a_ = {Ta[j], Ta[j + 1]}, b_ = {Tb[j], Tb[j + 1]};
+                    *reinterpret_cast<v2d*>(sh.prow + j) = a_;
+                    *reinterpret_cast<v2d*>(sh.prow + HALF + j) = b_;
+                }
+                sh.prow[CPT] = xb;
+            }
             RS_MARK_R(11);
             ++it;
             const bool last = it >= max_iter;   // :450: this pivot is applied, no further one is chosen
@@ -826,17 +851,26 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 inv = 1.0 / cc.ur;
                 lm = numm / cc.ur;
             }
+            if (!MIRROR) {
+                lds_barrier();   // ---- the pivot-row barrier
+                pl = sh.prow[lane <= CPT ? lane : 0];
+            }
             RS_MARK_R(16);
-            // reduced-cost row (row m of the tableau) after this pivot, replicated per wave: lane j takes pivot-row
-            // entry j (lane CPT: xB_r) from the staged copy; the wave-uniform entries needed below (xB_r and the
-            // candidate's) come out of these registers by v_readlane
-            const double* prow = sh.slots + cc.slot * SS;
-            const double pl = prow[lane <= CPT ? lane : 0];
+            // reduced-cost row (row m of the tableau) after this pivot, replicated per wave; the wave-uniform entries
+            // needed below (xB_r and the candidate's) come out of pl's registers by v_readlane
             const double pxb = lpdev::wave_bcast_f64(pl, CPT);
+            if (MIRROR && lane == 0)   // "my wave has read row r"
+                __hip_atomic_fetch_add(sh.readers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (colok) {
                 dl = (mycol == e) ? 0.0 : fma(lm, pl, dl);
-                if (mycol == e) nbl = false;
-                if (mycol == oldb) nbl = true;
+                if (basl && pl == 1.0) {   // N(r) leaves the basis (:196)
+                    basl = false;
+                    nbl = true;
+                }
+                if (mycol == e) {
+                    nbl = false;
+                    basl = true;
+                }
             }
             obj = fma(lm, pxb, obj);
             RS_MARK_R(12);
@@ -892,10 +926,17 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
                 }
             }
             const double le = (tid == r) ? inv : l;
+            if (MIRROR) {   // the pivot row out of pl's registers (v_readlane): no LDS, no barrier
 #pragma unroll
-            for (int j = 0; j < HALF; ++j) Ta[j] = fma(le, prow[j], Ta[j]);
+                for (int j = 0; j < HALF; ++j) Ta[j] = fma(le, lpdev::wave_bcast_f64(pl, j), Ta[j]);
 #pragma unroll
-            for (int j = 0; j < HALF; ++j) Tb[j] = fma(le, prow[HALF + j], Tb[j]);
+                for (int j = 0; j < HALF; ++j) Tb[j] = fma(le, lpdev::wave_bcast_f64(pl, HALF + j), Tb[j]);
+            } else {        // ... from its staged copy (broadcast reads)
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) Ta[j] = fma(le, sh.prow[j], Ta[j]);
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) Tb[j] = fma(le, sh.prow[HALF + j], Tb[j]);
+            }
             if (kst == k) {   // column e becomes the unit vector (selects on a wave-uniform condition, in place: an indexed
                               // register move made the compiler copy the slab to and fro; one workgroup per pivot gets here)
                 const double unit = (tid == r) ? 1.0 : 0.0;
@@ -908,6 +949,20 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
             }
             xb = xbn;
             up = upn;
+            if (MIRROR) {
+                if (wave == (r >> 6)) {   // my wave owns row r: every row wave must have read it from the mirror (long since)
+                    const unsigned want = (unsigned)nrw * (unsigned)it;
+                    Spin spin;
+                    while ((int)(__hip_atomic_load(sh.readers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
+                        if (spin.expired(cm.r, cm.abort)) {
+                            sh.ctl->fail = 9;   // code 9: mirror readers
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                RS_MIRROR_WRITE();
+            }
             RS_MARK_R(17);
             if (last) status = LP_ITER_LIMIT;
         }
@@ -985,7 +1040,11 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         de.nonbasic[col0 + lane] = nbl ? 1 : 0;
     }
     if (k == 0) {
-        for (int i = tid; i < de.m; i += (int)blockDim.x) de.basis[i] = sh.basis[i];
+        if (is_comm) {
+#pragma unroll
+            for (int q = 0; q < NBAS; ++q)
+                if (q * 64 + lane < de.m) de.basis[q * 64 + lane] = basv[q];
+        }
         if (tid == 0) {
             de.T[(size_t)de.m * de.ld + de.n] = obj;
             de.state->iters = it;
@@ -994,7 +1053,7 @@ __global__ __launch_bounds__(NT + 64) void k_simplex_resident(SimplexDev d, Resi
         }
     }
 #undef RS_SLAB_GET
-#undef RS_STAGE_ROW
+#undef RS_MIRROR_WRITE
 }
 
 __global__ void k_resident_state_init(SimplexDev d, double eps, int max_iter) {
