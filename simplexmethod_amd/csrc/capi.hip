@@ -374,7 +374,7 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     if (algo == LP_SIMPLEX_ALGO_AUTO)
         algo = p->res.G >= 1 ? LP_SIMPLEX_ALGO_RESIDENT
                : p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD
-               : lp_overlap_fits(p->dev.m) ? LP_SIMPLEX_ALGO_OVERLAP : LP_SIMPLEX_ALGO_LAUNCH;
+               : lp_overlap_auto(p->dev.m) ? LP_SIMPLEX_ALGO_OVERLAP : LP_SIMPLEX_ALGO_LAUNCH;
     if (algo == LP_SIMPLEX_ALGO_OVERLAP && asked_auto && lp_overlap_prepare(p) != LP_OPTIMAL) {
         (void)hipGetLastError();   // no memory for the second tableau buffer: the launch pair per pivot
         ctx->last_error.clear();

@@ -37,6 +37,7 @@ namespace {
 using namespace lptree;
 
 constexpr int kExpandParents = 64;  // parents per block of k_enum_expand (one slot allocation per block)
+constexpr int kStagedParents = 256; // ... of k_enum_expand_staged (16-row records): a lane per parent in all four waves
 
 // ---------------------------------------------------------------------------
 // phase 1: expand level t -> t+1 (records in HBM)
@@ -216,6 +217,9 @@ __global__ __launch_bounds__(256) void k_enum_expand(EnumDev d, PrefixDev pd, in
 // instructions).
 // ---------------------------------------------------------------------------
 // (4 waves per SIMD: 6 changed nothing, 8 spills and is 70 % slower)
+#ifndef LP_STAGED_COUNTED
+#define LP_STAGED_COUNTED 0
+#endif
 template <int NMXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_enum_expand_staged(EnumDev d, PrefixDev pd, int t,
                                                             const double* __restrict__ src, int src_cap,
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     constexpr int MAXC = NMXT + PGT + 1;            // columns of a record incl. the rhs: n - t + 1 <= m + NMXT + 1
     constexpr int PER = (MAXC * RS + META + 63) / 64;   // doubles per lane that hold one record's meaningful part + metadata
     using Meta = NodeMetaT<PGT>;
-    __shared__ int s_base[kExpandParents];
-    __shared__ int s_last[kExpandParents];
+    __shared__ int s_base[kStagedParents];
+    __shared__ int s_last[kStagedParents];
+    __shared__ int s_wtot[5];
+    __shared__ int s_nst[4];   // per wave: store instructions issued behind the prefetch in flight
     __shared__ __attribute__((aligned(16))) double s_rec[4][MAXC * RS + META];
     // subsets below a child with last column a: C(n-1-a, m-t-1) — one table per level, in LDS (looked up per
     // child by every parent's lane in phase A and again per lane in the expansion: out of L2 these dependent
@@ -244,7 +250,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int lim = n - m + t;  // largest column selectable at depth t
     __syncthreads();
     const size_t rdP = rec_doubles_g<PGT>(n, t, d.rs), rdC = rec_doubles_g<PGT>(n, t + 1, d.rs);
-    if (tid < 64) {   // phase A (as in k_enum_expand): children per parent, one slot allocation per block
+    {   // phase A: children per parent and ONE slot allocation per block — here over up to 256 parents, a lane each in
+        // all four waves (k_enum_expand: 64 parents by one wave while three wait).  Its three dependent round trips
+        // (the table above, the parents' metadata, the returning atomic: ~7 us) were a third of a 64-parent block's life.
         const int node = first + tid;
         int nch = 0, last = kHole;
         if (tid < 4 * ppw && node < nsrc) {
@@ -265,11 +273,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const int o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (lane == 63 && total > 0) base = atomicAdd(&pd.level_counts[t + 1], total);
-        base = __shfl(base, 63, 64);
-        s_base[tid] = base + incl - nch;
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int total = 0;
+            for (int w = 0; w < 4; ++w) {
+                const int x = s_wtot[w];
+                s_wtot[w] = total;   // exclusive prefix over the waves
+                total += x;
+            }
+            s_wtot[4] = total > 0 ? atomicAdd(&pd.level_counts[t + 1], total) : 0;
+        }
+        __syncthreads();
+        s_base[tid] = s_wtot[4] + s_wtot[wave] + incl - nch;
         s_last[tid] = nch > 0 ? last : kHole;   // (a parent without a child in the range is skipped like a hole)
     }
     __syncthreads();
@@ -286,9 +302,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int idx = u * 64 + lane;
+#if LP_STAGED_COUNTED
+            // (asm: a load the compiler does not track — the wait for it is the counted one at the staging below)
+            if (idx < cnt) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre[u]) : "v"(Q + idx) : "memory");
+#else
             pre[u] = idx < cnt ? Q[idx] : 0.0;
+#endif
         }
     };
+#if LP_STAGED_COUNTED
+#pragma unroll
+    for (int u = 0; u < PER; ++u) pre[u] = 0.0;
+    if (lane == 0) s_nst[wave] = 0;
+#endif
     fetch(0);
     for (int it = 0; it < ppw; ++it) {
         const int local = wave * ppw + it;
@@ -300,6 +326,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             continue;
         }
         const int cnt = (n - last) * RS + META;
+#if LP_STAGED_COUNTED
+        {
+            // The wave's memory counter retires loads and stores in issue order, and the compiler, not knowing how many
+            // stores the previous parent issued behind this parent's loads, would wait for ALL of them (vmcnt(0)): every
+            // parent then pays its predecessor's store acknowledgements, ~2-3 us.  The previous iteration counted the
+            // store instructions it issued at wave level (a lower bound: the column loops' trips and the rhs stores) —
+            // waiting until at most that many operations are outstanding retires exactly the loads and whatever is older.
+            const int nst = __builtin_amdgcn_readfirstlane(s_nst[wave]);
+            if (nst >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (nst >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (nst >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nst >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) s_nst[wave] = 0;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int idx = u * 64 + lane;
@@ -359,6 +401,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const double inv = 1.0 / piv;
             const bool isp = (gl == p);
             const double lx = isp ? inv : -(w * inv);
+#if LP_STAGED_COUNTED
+            {   // the groups that write a child this round: the first one has the smallest a, i.e. the longest column loop
+                const unsigned long long run = __ballot(1);
+                if (lane == (int)__builtin_ctzll(run)) s_nst[wave] += n - a;   // n - 1 - a columns + the rhs
+            }
+#endif
             double* Cc = C + (size_t)(a - t) * RS + gl;   // column c of the child at (c - t - 1) * RS
             const double* Lc = La + RS;                   // column a + 1 of the parent
 #pragma unroll 2
@@ -887,10 +935,13 @@ static int prefix_range_once(lp_enum_problem* p, uint64_t begin, uint64_t end, d
     } while (0)
         // wide levels of 16-row records: the parent staged in LDS (LP_ENUM_EXPAND_UNSTAGED=1: the earlier kernel, A/B)
         const bool unstaged = getenv("LP_ENUM_EXPAND_UNSTAGED") != nullptr;
+        // (the staged kernel of 16-row records: up to 64 parents per wave, 256 per block)
+        const int ppwS = (int)std::max<uint64_t>(1, std::min<uint64_t>(kStagedParents / 4, bound / ((uint64_t)ctx->num_cus * 32)));
+        const unsigned gridS = (unsigned)lp_ceil_div<uint64_t>(bound, 4 * (uint64_t)ppwS);
         if (shape == 1 && !narrow && !unstaged)
-            hipLaunchKernelGGL(k_enum_expand_staged<16>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
+            hipLaunchKernelGGL(k_enum_expand_staged<16>, gridS, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppwS, b, e);
         else if (shape == 2 && !narrow && !unstaged)
-            hipLaunchKernelGGL(k_enum_expand_staged<57>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
+            hipLaunchKernelGGL(k_enum_expand_staged<57>, gridS, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppwS, b, e);
         else if (shape == 3 && !narrow && !unstaged)
             hipLaunchKernelGGL(k_enum_expand_staged32<32>, grid, 256, 0, s, d, pd, t, src, src_cap, dst, cap, ppw, b, e);
         else if (shape == 1) LP_EXPAND(16, 16);

@@ -26,6 +26,7 @@ constexpr int kRunning = -100;  // SimplexState::status while pivoting
 constexpr int OV_TX = 64;    // column pairs per workgroup (128 columns: 1 KiB per row segment)
 constexpr int OV_TY = 16;    // row groups per workgroup
 constexpr int OV_RPT = 4;    // rows per thread
+constexpr int OV_LIN = 8;    // column pairs per thread in flight (linear update)
 
 struct OverlapDev {
     double* T[2];      // T[0] = SimplexDev::T; T_k lives in T[k & 1]
@@ -77,7 +78,7 @@ __device__ __forceinline__ void overlap_select(const SimplexDev& d, const Overla
     const bool prev = k > 0 && in[2] != 0;       // pivot k is pending on T_{k-1} (applied by this launch's other workgroups)
     const int ep = in[0], rp = in[1];
     const double* lp = ov.lcol[cur];
-    const double* pp = ov.prow[cur];
+    const double* pp = Ts + (size_t)(prev ? rp : 0) * ld;   // pivot k's row: row r_k of T_{k-1} itself
     // entry (i, j) of T_k: what the update writes there (simplex_launch.hip: k_simplex_update, operand for operand)
     auto val = [&](int i, int j) {
         double v = Ts[(size_t)i * ld + j];
@@ -151,10 +152,9 @@ __device__ __forceinline__ void overlap_select(const SimplexDev& d, const Overla
     }
     const double ur = s_u[r];
     double* lout = ov.lcol[nxt];
-    double* pout = ov.prow[nxt];
     for (int i = tid; i <= m; i += blockDim.x)  // F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204
         lout[i] = (i == r) ? 1.0 / ur : -s_u[i] / ur;
-    for (int j = tid; j < ld; j += blockDim.x) pout[j] = val(r, j);
+    // (the pivot row of pivot k+1 is row r of T_k: the next launch reads it there)
     if (tid == 0) {
         const int old = d.basis[r];
         d.basis[r] = e;  // N(leave_pos) = enter, :196
@@ -175,32 +175,297 @@ __device__ __forceinline__ void overlap_select(const SimplexDev& d, const Overla
     }
 }
 
+// The same selection with TWO dependent global round trips instead of six (round 4; the selector shares the chip
+// with an update that saturates the memory system, so every dependent access costs microseconds: 2048 x 4096 ran
+// at 27.8 us per pivot for a 22 us update).  For m + 1 <= OVF_ROWS * 1024 rows and an LDS budget that still lets two
+// update workgroups share a CU:
+//   trip 1  everything that does not depend on the entering column, all in flight together: the cost row, the
+//           non-basic flags and pivot k's row (pricing), pivot k's eta column and the xB column (ratio test) —
+//           the priced values go to LDS (they were staged in global memory and read back), xB stays in registers;
+//   trip 2  the entering column (strided gather) -> u, ratios, the ratio chain in LDS; the eta column comes out of the
+//           registers that hold u.
+// The pivot row is not copied any more: pivot k's row is row r_k of T_{k-1}, where both this selection and the update
+// read it.
+constexpr int OVF_ROWS = 4;    // rows per thread held in registers
+constexpr int OVF_COLS = 4;    // columns per thread and chunk of 4096
+
+__device__ __forceinline__ void overlap_select_fast(const SimplexDev& d, const OverlapDev& ov, int k, double* s_dyn) {
+    SimplexState* st = d.state;
+    const int m = d.m, n = d.n, ld = d.ld;
+    double* s_u = s_dyn;
+    double* s_ratio = s_dyn + (m + 2);
+    int* s_int = reinterpret_cast<int*>(s_dyn + 2 * (m + 2));
+    int& s_enter = s_int[0];
+    int& s_leave = s_int[1];
+    int& s_flag = s_int[2];
+    lpdev::BlockChainScratch* s_sc = reinterpret_cast<lpdev::BlockChainScratch*>(s_dyn + 2 * (m + 2) + 2);
+    double* s_price = reinterpret_cast<double*>(s_sc + 1);   // n doubles
+    const int tid = threadIdx.x, T = (int)blockDim.x;
+    const int cur = k & 1, nxt = cur ^ 1;
+    int* out = ov.slot + 4 * nxt;
+    const double* Ts = ov.T[k == 0 ? 0 : nxt];   // T_{k-1}
+    const int* in = ov.slot + 4 * cur;
+    const double* lp = ov.lcol[cur];
+    // ---- trip 1: issued before anything is looked at (reads only; an early exit simply drops them)
+    const int status = st->status, iters = st->iters, max_iter = st->max_iter;
+    const double eps = st->eps;
+    const int in_valid = in[2], ep = in[0], rp = in[1];
+    const double* pp = Ts + (size_t)((k > 0 && in_valid != 0) ? rp : 0) * ld;   // pivot k's row: row r_k of T_{k-1} itself
+    const double lpm = lp[m], ppn = pp[n];
+    double xb_raw[OVF_ROWS], lrow[OVF_ROWS];
+#pragma unroll
+    for (int q = 0; q < OVF_ROWS; ++q) {
+        const int i = tid + q * T;
+        xb_raw[q] = (i <= m) ? Ts[(size_t)i * ld + n] : 0.0;
+        lrow[q] = (i <= m) ? lp[i] : 0.0;
+    }
+    if (status != kRunning) {
+        if (tid == 0) out[2] = 0;
+        return;
+    }
+    if (iters >= max_iter) {  // while (iteration < MAX_ITER) ... throw, :429,:450
+        if (tid == 0) {
+            st->status = LP_ITER_LIMIT;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    const bool prev = k > 0 && in_valid != 0;    // pivot k is pending on T_{k-1} (applied by this launch's other workgroups)
+    // entry (i, j) of T_k from its three operands: what the update writes there (k_simplex_update, operand for operand)
+    auto upd = [&](double v, double l, double pr, int i, int j) {
+        if (prev) {
+            v = (i == rp) ? pr * l : fma(l, pr, v);
+            if (j == ep) v = (i == rp) ? 1.0 : 0.0;
+        }
+        return v;
+    };
+    // pricing: the updated cost row -> LDS
+    const double ineligible = d.maximize ? -INFINITY : INFINITY;   // complement(), :97-108
+    for (int base = 0; base < n; base += OVF_COLS * T) {
+        double cr[OVF_COLS], pr[OVF_COLS];
+        unsigned char nb[OVF_COLS];
+#pragma unroll
+        for (int q = 0; q < OVF_COLS; ++q) {
+            const int j = base + tid + q * T;
+            const int jc = j < n ? j : n - 1;
+            cr[q] = Ts[(size_t)m * ld + jc];
+            pr[q] = pp[jc];
+            nb[q] = d.nonbasic[jc];
+        }
+#pragma unroll
+        for (int q = 0; q < OVF_COLS; ++q) {
+            const int j = base + tid + q * T;
+            if (j < n) {
+                double v = nb[q] != 0 ? upd(cr[q], lpm, pr[q], m, j) : ineligible;
+                s_price[j] = (v == v) ? v : ineligible;
+            }
+        }
+    }
+    // xB of T_k (column n is never the entering column)
+    double xbv[OVF_ROWS];
+#pragma unroll
+    for (int q = 0; q < OVF_ROWS; ++q) xbv[q] = upd(xb_raw[q], lrow[q], ppn, tid + q * T, n);
+    __syncthreads();
+    {
+        double best;
+        int e;
+        auto price = [&](int j) { return s_price[j]; };
+        if (d.maximize)
+            e = lpdev::block_chain_select<true, false>(n, eps, best, price, s_price, s_sc);
+        else
+            e = lpdev::block_chain_select<false, false>(n, eps, best, price, s_price, s_sc);
+        const bool optimal = d.maximize ? (best <= eps) : (best >= -eps);  // :162 / :173
+        if (tid == 0) {
+            s_enter = optimal ? -1 : e;
+            s_flag = 0;
+        }
+    }
+    __syncthreads();
+    const int e = s_enter;
+    if (e < 0) {
+        if (tid == 0) {
+            st->status = LP_OPTIMAL;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    // ---- trip 2: u = Binv * A.col(enter), :176, incl. the reduced-cost row
+    const double ppe = pp[e];
+    double uu[OVF_ROWS];
+#pragma unroll
+    for (int q = 0; q < OVF_ROWS; ++q) {
+        const int i = tid + q * T;
+        uu[q] = (i <= m) ? Ts[(size_t)i * ld + e] : 0.0;
+    }
+    int any_pos = 0;
+#pragma unroll
+    for (int q = 0; q < OVF_ROWS; ++q) {
+        const int i = tid + q * T;
+        if (i <= m) {
+            const double ui = upd(uu[q], lrow[q], ppe, i, e);
+            uu[q] = ui;
+            s_u[i] = ui;
+            if (i < m) {
+                s_ratio[i] = (ui > eps) ? xbv[q] / ui : INFINITY;  // :185-186
+                if (!(ui <= eps)) any_pos = 1;  // (u.array() <= EPS).all(), :179
+            }
+        }
+    }
+    if (any_pos) s_flag = 1;
+    __syncthreads();
+    if (!s_flag) {
+        if (tid == 0) {
+            st->status = LP_UNBOUNDED;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    {
+        double theta;
+        auto ratio = [&](int i) { return s_ratio[i]; };   // ineligible rows hold +inf, which the < scan never takes
+        const int r = lpdev::block_chain_select<false, false>(m, eps, theta, ratio, s_ratio, s_sc);  // :187-190
+        if (tid == 0) s_leave = r;
+    }
+    __syncthreads();
+    const int r = s_leave;
+    if (r < 0) {  // :194
+        if (tid == 0) {
+            st->status = LP_UNBOUNDED;
+            st->pivot_valid = 0;
+            out[2] = 0;
+        }
+        return;
+    }
+    // (no third trip: the pivot row of pivot k+1 is row r of T_k, which the next launch reads where this launch's
+    // update workgroups are writing it)
+    const double ur = s_u[r];
+    double* lout = ov.lcol[nxt];
+#pragma unroll
+    for (int q = 0; q < OVF_ROWS; ++q) {  // F(i,r) = -u_i/u_r, F(r,r) = 1/u_r, :198-204
+        const int i = tid + q * T;
+        if (i <= m) lout[i] = (i == r) ? 1.0 / ur : -uu[q] / ur;
+    }
+    if (tid == 0) {
+        const int old = d.basis[r];
+        d.basis[r] = e;  // N(leave_pos) = enter, :196
+        d.nonbasic[e] = 0;
+        d.nonbasic[old] = 1;
+        if (iters < d.trace_cap) {
+            d.trace_enter[iters] = e;
+            d.trace_leave[iters] = r;
+        }
+        st->iters = iters + 1;
+        st->enter = e;
+        st->leave = r;
+        st->pivot_valid = 1;
+        out[0] = e;
+        out[1] = r;
+        out[2] = 1;
+    }
+}
+
 // Launch k.  nbx = column tiles of the update (its workgroups are 1 ... nbx * nby).
-__global__ __launch_bounds__(OV_TX* OV_TY) void k_simplex_overlap(SimplexDev d, OverlapDev ov, int k, int nbx, int dbg) {
+template <bool LINEAR>
+__global__ __launch_bounds__(OV_TX* OV_TY) void k_simplex_overlap(SimplexDev d, OverlapDev ov, int k, int nbx, int fast) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     if (blockIdx.x == 0) {
         __builtin_amdgcn_s_setprio(3);
-        overlap_select(d, ov, k, s_dyn);
+#ifdef LP_OVERLAP_UPDATE_ONLY   // diagnostic builds: after the first real selection every launch repeats pivot 1's eta
+        if (k >= 2) {           // (numerically meaningless: the out-of-place update's own time per launch)
+            if (threadIdx.x == 0) {
+                SimplexState* st = d.state;
+                int* o = ov.slot + 4 * ((k & 1) ^ 1);
+                const int* in = ov.slot + 4 * (k & 1);
+                if (st->status != kRunning) { o[2] = 0; return; }
+                if (st->iters >= st->max_iter) { st->status = LP_ITER_LIMIT; o[2] = 0; return; }
+                st->iters = st->iters + 1;
+                o[0] = in[0]; o[1] = in[1]; o[2] = in[2];
+            }
+            return;
+        }
+#endif
+        if (fast)
+            overlap_select_fast(d, ov, k, s_dyn);
+        else
+            overlap_select(d, ov, k, s_dyn);
         return;
     }
-    if (k == 0 || dbg == 1) return;
+    if (k == 0) return;
+#ifdef LP_OVERLAP_SELECT_ONLY   // diagnostic builds (scripts/ab_overlap_variants): the selection's own time per launch
+    return;
+#endif
     const int cur = k & 1;
     const int* sl = ov.slot + 4 * cur;
     if (!sl[2]) return;
     const int e = sl[0], r = sl[1];
-    const int b = (int)blockIdx.x - 1;
-    const int by = b / nbx, bx = b - by * nbx;
-    const int tx = threadIdx.x & (OV_TX - 1), ty = threadIdx.x / OV_TX;
     const int ld2 = d.ld >> 1;
-    const int jp = bx * OV_TX + tx;  // column pair
-    if (jp >= ld2) return;
     const int rows = d.m + 1;
-    const double2 pr = reinterpret_cast<const double2*>(ov.prow[cur])[jp];
     const double2* S2 = reinterpret_cast<const double2*>(ov.T[cur ^ 1]);
     double2* D2 = reinterpret_cast<double2*>(ov.T[cur]);
     const double* lcol = ov.lcol[cur];
-    const int i0 = (by * OV_TY + ty) * OV_RPT;
     const int je = e >> 1;
+    if constexpr (LINEAR) {
+        // Few tiles for the chip (fewer than three rounds of the 2 x 256 resident workgroups: at 2048 x 4096 the 1089
+        // tiles are 2.13 rounds, the third one 13 % full — 26.6 us per launch against the 22.7 of the stand-alone
+        // kernel's 4257 small workgroups): the update workgroups are PERSISTENT and share the tableau evenly and
+        // linearly instead — workgroup w streams the contiguous piece [G w / W, G (w+1) / W) of the row-major tableau
+        // (G 16-byte column pairs), four per thread in flight; the pivot-row pair and the eta entry of each come from
+        // L1/L2 (row r and the eta column are 50 KB, hot): 24.2 us.  On larger tableaus the tiles win (a loop's
+        // iterations do not overlap: 3072 x 6144 57 us in tiles, 72 linear): the other instantiation of this kernel.
+        const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
+        const int T = OV_TX * OV_TY;
+        const double2* P2 = S2 + (size_t)r * ld2;   // the pivot row: row r of T_{k-1}
+        const long long G = (long long)rows * ld2;
+        const long long g0 = G * w / W, g1 = G * (w + 1) / W;
+        for (long long gb = g0 + threadIdx.x; gb < g1; gb += (long long)T * OV_LIN) {
+            double2 t[OV_LIN], pr[OV_LIN];
+            double l[OV_LIN];
+            int ii[OV_LIN], jj[OV_LIN];
+#pragma unroll
+            for (int q = 0; q < OV_LIN; ++q) {
+                const long long g = gb + (long long)q * T;
+                ii[q] = (int)(g / ld2);
+                jj[q] = (int)(g - (long long)ii[q] * ld2);
+                if (g < g1) {
+                    t[q] = S2[g];
+                    pr[q] = P2[jj[q]];
+                    l[q] = lcol[ii[q]];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < OV_LIN; ++q) {
+                const long long g = gb + (long long)q * T;
+                if (g < g1) {
+                    const int i = ii[q], jp = jj[q];
+                    double2 v = t[q];
+                    if (i == r) {
+                        v.x = pr[q].x * l[q];
+                        v.y = pr[q].y * l[q];
+                    } else {
+                        v.x = fma(l[q], pr[q].x, v.x);
+                        v.y = fma(l[q], pr[q].y, v.y);
+                    }
+                    if (jp == je) {
+                        const double unit = (i == r) ? 1.0 : 0.0;
+                        if (e & 1) v.y = unit; else v.x = unit;
+                    }
+                    D2[g] = v;
+                }
+            }
+        }
+        return;
+    }
+    // ---- one tile of 128 columns x 64 rows per workgroup
+    const int b = (int)blockIdx.x - 1;
+    const int by = b / nbx, bx = b - by * nbx;
+    const int tx = threadIdx.x & (OV_TX - 1), ty = threadIdx.x / OV_TX;
+    const int jp = bx * OV_TX + tx;  // column pair
+    if (jp >= ld2) return;
+    const double2 pr = S2[(size_t)r * ld2 + jp];   // the pivot row: row r of T_{k-1}
+    const int i0 = (by * OV_TY + ty) * OV_RPT;
     double2 t[OV_RPT];
     double l[OV_RPT];
 #pragma unroll
@@ -235,9 +500,17 @@ __global__ __launch_bounds__(OV_TX* OV_TY) void k_simplex_overlap(SimplexDev d, 
 }  // namespace
 
 size_t lp_overlap_lds_bytes(int m) { return 2 * sizeof(double) * (size_t)(m + 2) + 16 + sizeof(lpdev::BlockChainScratch); }
+// the three-round-trip selector: the priced cost row in LDS too, rows in registers — if that still leaves room for
+// two update workgroups per CU (every workgroup of the launch is given the selector's dynamic LDS)
+static bool overlap_fast_fits(int m, int n) {
+    return m + 1 <= OVF_ROWS * OV_TX * OV_TY && lp_overlap_lds_bytes(m) + sizeof(double) * (size_t)n <= 78 * 1024;
+}
 
 // The shape runs on this path if the selector's two m-vectors fit one CU's LDS.
 bool lp_overlap_fits(int m) { return lp_overlap_lds_bytes(m) <= 156 * 1024; }
+// What AUTO takes: every workgroup of the launch is given the selector's dynamic LDS, so beyond 80 KB (m ~ 5000) the
+// update would run ONE workgroup per CU — never measured; the launch pair per pivot has no such coupling.
+bool lp_overlap_auto(int m) { return lp_overlap_lds_bytes(m) <= 80 * 1024; }
 
 // Second tableau and second eta slot, on first use (each checked on its own: a failed second allocation must not
 // leave a later call with the first one only).  AUTO calls this before it commits to the algorithm: without the
@@ -267,26 +540,35 @@ int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_s
     ov.prow[1] = p->ov_vec;                         // ld doubles (16-byte aligned: read as double2)
     ov.lcol[1] = p->ov_vec + d.ld;                  // m + 2 doubles
     ov.slot = reinterpret_cast<int*>(p->ov_vec + d.ld + d.m + 2);   // 8 ints
-    const size_t shm = lp_overlap_lds_bytes(d.m);
+    const int fast = overlap_fast_fits(d.m, d.n) ? 1 : 0;
+    const size_t shm = lp_overlap_lds_bytes(d.m) + (fast ? sizeof(double) * (size_t)d.n : 0);
     if (shm > 48 * 1024 && !p->ov_attr) {
-        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_overlap),
+        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_overlap<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        LP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_simplex_overlap<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         p->ov_attr = true;
     }
-    const int nbx = lp_ceil_div(d.ld / 2, OV_TX), nby = lp_ceil_div(d.m + 1, OV_TY * OV_RPT);
-    const unsigned grid = 1u + (unsigned)nbx * (unsigned)nby;
+    const int nbx = lp_ceil_div(d.ld / 2, OV_TX);
+    const int nby = lp_ceil_div(d.m + 1, OV_TY * OV_RPT);
+    // the update: a tile per workgroup, or — fewer than three rounds of tiles on the resident workgroups (two of 1024
+    // threads per CU) — persistent workgroups with even linear shares (see the kernel)
+    const int linear = (nbx * nby < 6 * ctx->num_cus) ? 1 : 0;
+    const unsigned grid = 1u + (unsigned)(linear ? std::max(1, std::min(nbx * nby, 2 * ctx->num_cus - 1)) : nbx * nby);
     int launches = 0;
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_overlap_init, 1, 1, 0, s, d, ov, eps, max_iter);
     ++launches;
     int batch = 16, k = 0;
     int status = kRunning;
-    const int dbg = 0;   // (1: selection only — timing experiments of diagnostic builds)
     // Launches turn into no-ops once the state leaves kRunning, so they are queued in growing batches and
     // the status word is polled once per batch.
     for (;;) {
         for (int q = 0; q < batch; ++q, ++k)
-            hipLaunchKernelGGL(k_simplex_overlap, grid, OV_TX * OV_TY, shm, s, d, ov, k, nbx, dbg);
+            if (linear)
+                hipLaunchKernelGGL(k_simplex_overlap<true>, grid, OV_TX * OV_TY, shm, s, d, ov, k, nbx, fast);
+            else
+                hipLaunchKernelGGL(k_simplex_overlap<false>, grid, OV_TX * OV_TY, shm, s, d, ov, k, nbx, fast);
         launches += batch;
         LP_HIP(ctx, hipMemcpyAsync(p->h_state, d.state, sizeof(SimplexState), hipMemcpyDeviceToHost, s));
         LP_HIP(ctx, hipStreamSynchronize(s));

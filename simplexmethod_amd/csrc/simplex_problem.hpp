@@ -105,6 +105,7 @@ int lp_simplex_bench_update(lp_simplex_problem* p, int row, int col, int iters, 
 
 // simplex_overlap.hip
 bool lp_overlap_fits(int m);
+bool lp_overlap_auto(int m);    // what LP_SIMPLEX_ALGO_AUTO requires of the shape
 int lp_overlap_prepare(lp_simplex_problem* p);   // allocates the second tableau buffer (first use)
 int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_simplex_stats* stats);
 
