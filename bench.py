@@ -66,11 +66,11 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_PROFILE = "r03_pmc_traffic.json"
+PMC_PROFILE = "r04_pmc_traffic.json"
 
 
 def pmc_profile():
-    """profiles/r03_pmc_traffic.json (written by scripts/pmc_to_json.py from separate rocprofv3 --pmc
+    """profiles/r04_pmc_traffic.json (written by scripts/pmc_to_json.py from separate rocprofv3 --pmc
     passes: FETCH_SIZE and WRITE_SIZE of scripts/pmc_traffic.py, the VALU and fp64 instruction counters of
     scripts/pmc_enum.py; plus the rocprofv3 --kernel-trace average of k_simplex_update): HBM bytes per
     launch of the tableau kernels, executed fp64 operations per enumerated subset.  bench.py cannot run
@@ -135,9 +135,9 @@ def pivot_leg(ctx, args):
     phases = None
     if resident and (m, n) == (512, 1024):
         try:
-            mk = json.load(open(os.path.join(ROOT, "profiles", "r03_resident_marks.json")))
+            mk = json.load(open(os.path.join(ROOT, "profiles", "r04_resident_marks.json")))
             if mk.get("kernel_source_hash") == kernel_source_hash():
-                phases = {"source": "profiles/r03_resident_marks.json (scripts/resident_marks.py)",
+                phases = {"source": "profiles/r04_resident_marks.json (scripts/resident_marks.py)",
                           "cycles_per_pivot_mean_over_workgroups": mk["intervals"],
                           "critical_path_cycles_per_pivot": mk.get("critical_path_cycles_per_pivot")}
         except Exception:
@@ -219,8 +219,8 @@ def pivot_leg(ctx, args):
         k = bytes_per_pivot * pivots / (auto["kernel_ms"] * 1e-3) / 1e9
         roofline = {
             "kernel": "k_simplex_resident (every pivot of the solve in ONE launch: the tableau stays in the "
-                      "registers of ceil(n/32) co-resident workgroups; per pivot one all-to-all hand-off of "
-                      "a 32-byte record and a 4 KB column per workgroup through L2)",
+                      "registers of ceil(n/32) co-resident workgroups; per pivot one all-to-all hand-off through L2: a 16-byte "
+                      "pricing record, eight 32-byte ratio-test slice records and an 8 KB candidate column per workgroup)",
             "bound": "handoff-latency", "roofline_it_is_priced_against": "hbm",
             "achieved": round(k, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(k / HBM_PEAK_GBS, 4), "traffic": traffic_of(prof, "k_simplex_resident"),
@@ -253,14 +253,14 @@ def large_shape_leg(ctx, args):
     names = {capi.SIMPLEX_LAUNCH: "launch", capi.SIMPLEX_LOOKAHEAD: "lookahead", capi.SIMPLEX_RESIDENT: "resident",
              capi.SIMPLEX_OVERLAP: "overlap"}
 
-    def run(algo):
-        best = None
+    def run(algo):   # (mean of 3 solves: what the roofline is computed from)
+        acc, last = 0.0, None
         for _ in range(3):
             p.reset()
             rc, st = p.run(algo=algo, max_iter=piv)
-            if best is None or st.solve_ms < best[0]:
-                best = (st.solve_ms, st.pivots, int(st.algo_used), int(st.launches))
-        return best
+            acc += st.solve_ms
+            last = st
+        return (acc / 3.0, last.pivots, int(last.algo_used), int(last.launches))
     auto = run(capi.SIMPLEX_AUTO)
     two = run(capi.SIMPLEX_LAUNCH)
     p.reset()
@@ -268,6 +268,7 @@ def large_shape_leg(ctx, args):
     p.free()
     us = 1e3 * auto[0] / max(auto[1], 1)
     rate = bytes_per_pivot / us / 1e3
+    traffic = traffic_of(pmc_profile(), "k_simplex_overlap")   # HBM bytes per launch (= per pivot) from the PMC passes, same sources only
     upd = bytes_per_pivot / (upd_ms * 1e3) / 1e3
     return {
         "workload": f"simplex m={m} n={n} seed 0, first {piv} pivots (tableau {8e-6 * (m + 1) * (n + 1):.0f} MB)",
@@ -275,7 +276,9 @@ def large_shape_leg(ctx, args):
         "us_per_pivot": round(us, 3),
         "roofline": {"what": "whole pivot (selection overlapped with the update), algorithmic bytes / time",
                      "bound": "hbm", "achieved": round(rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(rate / HBM_PEAK_GBS, 4)},
+                     "frac": round(rate / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_over_algorithmic_bytes": None if traffic is None else round(traffic / bytes_per_pivot, 3),
+                     "algorithmic_bytes_per_launch": bytes_per_pivot},
         "two_launches_per_pivot_us": round(1e3 * two[0] / max(two[1], 1), 3),
         "rank1_update_kernel_alone": {"kernel": "k_simplex_update (in place)", "avg_launch_us": round(1e3 * upd_ms, 3),
                                       "achieved": round(upd, 1), "unit": "GB/s", "frac": round(upd / HBM_PEAK_GBS, 4),

@@ -1,4 +1,4 @@
-"""profiles/r03_pmc_traffic.json from the two PMC passes of scripts/pmc_traffic.py.
+"""profiles/r04_pmc_traffic.json from the two PMC passes of scripts/pmc_traffic.py.
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KB, and on
 gfx950 FETCH_SIZE reads exactly half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash)
 
 KERNELS = {"k_simplex_resident": "k_simplex_resident", "k_simplex_update": "k_simplex_update",
-           "k_look_update": "k_look_update"}
+           "k_look_update": "k_look_update", "k_simplex_overlap": "k_simplex_overlap"}
 
 
 def per_kernel(directory, counter):
@@ -32,7 +32,8 @@ def per_kernel(directory, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"kernel_source_hash": bench.kernel_source_hash(),
-       "workload": "scripts/pmc_traffic.py: m=512 n=1024 seed 0",
+       "workload": "scripts/pmc_traffic.py: m=512 n=1024 seed 0; k_simplex_overlap: m=2048 n=4096 seed 0, first 40 pivots "
+                   "(one launch per pivot: the out-of-place rank-1 update of the 67 MB tableau + the next selection)",
        "formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "kernels": {}}
 for k in KERNELS:

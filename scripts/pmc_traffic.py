@@ -21,3 +21,10 @@ print("rank-1 ms/launch", p.bench_update(0, 0, 50))
 p.reset()
 print("rank-J (ms/launch, J)", p.bench_update_rankj(50))
 p.free()
+# the one-launch-per-pivot path on a tableau that streams (2048 x 4096, 67 MB): k_simplex_overlap, one launch per pivot
+m, n = 2048, 4096
+A, b, c, basis = capi.gen_lp(0, m, n)
+p = ctx.simplex_problem(A, b, c, basis, True, n - m)
+rc, st = p.run(algo=capi.SIMPLEX_OVERLAP, max_iter=40)
+print("overlap 2048x4096: rc", rc, "pivots", st.pivots, "launches", st.launches, "solve ms", st.solve_ms)
+p.free()

@@ -23,6 +23,8 @@ def main():
     trials, pivots, statuses = 0, 0, {}
     while time.time() < t_end:
         m = int(rng.integers(1, 160)) if rng.integers(0, 4) else int(rng.integers(160, 513))
+        if rng.integers(0, 12) == 0:
+            m = int(rng.integers(513, 961))   # 16 columns per workgroup, the LDS mirror of the slab (simplex_resident.hip: MIRROR)
         no = int(rng.integers(1, 2 * m + 2))
         n = no + m
         kind = int(rng.integers(0, 3))

@@ -729,8 +729,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             // ---- this wave's share of the eta column (:198-204)
             // (one division per entry: F(r,r) = 1/u_r and F(i,r) = -u_i/u_r share the divisor, :201-204)
             const double ur = ucol[r];
-            for (int i = tid; i < m; i += NT) lcol[i] = ((i == r) ? 1.0 : -ucol[i]) / ur;
-            if (tid == 0) lcol[mp] = -drow[se] / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = lpdev::div_midrange((i == r) ? 1.0 : -ucol[i], ur);   // (the division's bits, a third of its instructions)
+            if (tid == 0) lcol[mp] = lpdev::div_midrange(-drow[se], ur);
             BR_STAMP(4);
             __syncthreads();   // (4) eta column and pivot row complete
             BR_STAMP(5);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 1) void k_batched_simplex_reg(B
             // ---- eta column (:198-204) and the pivot row, from the owners' registers
             // (one division per entry: F(r,r) = 1/u_r and F(i,r) = -u_i/u_r share the divisor, :201-204)
             const double ur = ucol[r];
-            for (int i = tid; i < m; i += NT) lcol[i] = ((i == r) ? 1.0 : -ucol[i]) / ur;
+            for (int i = tid; i < m; i += NT) lcol[i] = lpdev::div_midrange((i == r) ? 1.0 : -ucol[i], ur);   // (the division's bits, a third of its instructions)
             const int gr = r / RPT, kr = r % RPT;
             if (upd && g == gr) {
                 // (kr is uniform: a switch reaches the one row with a scalar branch tree — 44 predicated

@@ -505,4 +505,12 @@ __device__ __forceinline__ bool mid_range(double v) {   // 2^-500 <= |v| < 2^501
 }
 __device__ __forceinline__ bool mid_range_or_zero(double v) { return v == 0.0 || mid_range(v); }
 
+// num / den for every active lane — the same bits — by the sequence above while every active lane's operands are
+// inside its range, by the plain division otherwise (one wave-uniform branch)
+__device__ __forceinline__ double div_midrange(double num, double den) {
+    const double q = mid_div(num, den, mid_recip2(den));
+    if (__builtin_expect(!__all(mid_range(den) && mid_range_or_zero(num)), 0)) return num / den;
+    return q;
+}
+
 }  // namespace lpdev
