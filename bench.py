@@ -253,7 +253,9 @@ def large_shape_leg(ctx, args):
     names = {capi.SIMPLEX_LAUNCH: "launch", capi.SIMPLEX_LOOKAHEAD: "lookahead", capi.SIMPLEX_RESIDENT: "resident",
              capi.SIMPLEX_OVERLAP: "overlap"}
 
-    def run(algo):   # (mean of 3 solves: what the roofline is computed from)
+    def run(algo):   # (mean of 3 solves behind a warm-up that takes the path's one-time allocations: the second tableau)
+        p.reset()
+        p.run(algo=algo, max_iter=piv)
         acc, last = 0.0, None
         for _ in range(3):
             p.reset()

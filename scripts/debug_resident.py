@@ -1,4 +1,5 @@
-"""Diagnostic: repeated chip-resident solves under the experiment switches; counts hand-off timeouts."""
+"""Diagnostic: repeated chip-resident solves in the placement-dependent forms (participants spread over all XCDs,
+write-through stores forced); counts hand-off timeouts (LP_RESIDENT_DEBUG=1: the library dumps the pricing-record area)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["LP_RESIDENT_STRICT"] = "1"
@@ -9,9 +10,7 @@ probs = []
 for seed, m, n in [(0, 512, 1024)]:
     A, b, c, basis = lpcases.random_lp(seed, m, n)
     probs.append((m, n, ctx.simplex_problem(A, b, c, basis, True, n - m)))
-for mode in ([], ["LP_RESIDENT_DRAIN"], ["LP_RESIDENT_ONESWEEP"], ["LP_RESIDENT_DRAIN", "LP_RESIDENT_ONESWEEP"],
-             ["LP_RESIDENT_PUBL"], ["LP_RESIDENT_SPREAD"], ["LP_RESIDENT_SPREAD", "LP_RESIDENT_DRAIN"], ["LP_RESIDENT_FORCE_SC1"],
-             ["LP_RESIDENT_FORCE_SC1", "LP_RESIDENT_DRAIN"]):
+for mode in ([], ["LP_RESIDENT_SPREAD"], ["LP_RESIDENT_FORCE_SC1"], ["LP_RESIDENT_SPREAD", "LP_RESIDENT_FORCE_SC1"]):
     for v in mode:
         os.environ[v] = "1"
     for m, n, p in probs:

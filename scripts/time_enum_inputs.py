@@ -1,9 +1,5 @@
 """Enumeration C(n,m) on several inputs (three seeds, the fully degenerate b = 0 LP, a half-degenerate
-one): wall time of pass 1 + tie rule, kernel time of pass 1, counts.  LP_ENUM_EVAL_DIRECT=1 evaluates the
-feasible list with from-scratch solves (A/B against the record-based evaluator).
-
-    python scripts/time_enum_inputs.py [m n]
-"""
+one): wall time of pass 1 + tie rule, kernel time of pass 1, counts."""
 import os
 import sys
 import time

@@ -154,6 +154,21 @@ def test_overlap_large_shape(ctx, max_iter):
     _assert_bit_exact(g, r)
 
 
+@pytest.mark.parametrize("max_iter", [2, 3])
+def test_overlap_general_selector_and_tiled_update(ctx, max_iter):
+    """1100 x 11000 (97 MB): the one-launch-per-pivot path in its OTHER forms — the priced cost row does not fit LDS
+    beside the selector's vectors, so the general selector runs (staging in global memory), and 1548 tiles are more
+    than three rounds of the resident workgroups, so the update takes one tile per workgroup instead of persistent
+    linear shares.  Same pivots and the same tableau, bit for bit, as the oracle, after an even and an odd number of
+    pivots (the tableau alternates between two buffers)."""
+    m, n = 1100, 11000
+    A, b, c, basis = lpcases.random_lp(48, m, n)
+    r = o.simplex_tableau(A, b, c, basis, True, n - m, trace_cap=64, want_tableau=True, max_iter=max_iter)
+    assert r["status"] == o.ITER_LIMIT and r["iters"] == max_iter
+    g = _run(ctx, A, b, c, basis, True, n - m, trace_cap=64, max_iter=max_iter, algo=capi.SIMPLEX_OVERLAP)
+    _assert_bit_exact(g, r)
+
+
 def test_resident_fallback_is_visible(ctx, monkeypatch):
     """A hand-off failure (injected: the placement census reports one) must be impossible to miss: with
     LP_RESIDENT_STRICT (the whole GPU session) the run returns an error; without it the solve is re-run on
