@@ -12,13 +12,15 @@ def build(specs):
     b.build_hip()
     os.makedirs(AB, exist_ok=True)
     obj_dir = os.path.join(b.OUT, "obj")
-    others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and f != "simplex_resident.o"]
     flags = [f for f in b.HIPCC_FLAGS if f != "-shared"]
     for spec in specs:
         name, _, defs = spec.partition("=")
+        name, _, stem = name.partition("@")      # NAME@simplex_overlap=-D... builds a variant of another source file
+        stem = stem or "simplex_resident"
+        others = [os.path.join(obj_dir, f) for f in sorted(os.listdir(obj_dir)) if f.endswith(".o") and f != stem + ".o"]
         obj = os.path.join(AB, "var_%s.o" % name)
         lib = os.path.join(AB, "libvar_%s.so" % name)
-        subprocess.run([b.hipcc_path()] + flags + defs.split() + ["-c", "-o", obj, os.path.join(b.CSRC, "simplex_resident.hip")], check=True)
+        subprocess.run([b.hipcc_path()] + flags + defs.split() + ["-c", "-o", obj, os.path.join(b.CSRC, stem + ".hip")], check=True)
         subprocess.run([b.hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + others + ["-ldl", "-pthread"], check=True)
         os.remove(obj)
         print("built", lib, flush=True)

@@ -1,27 +1,36 @@
-"""C(32,16) seed 0 full pass (and the 8-way shards' slowest) on the library named by LP_LIB_PATH: ms per pass,
-counts and optimum for comparison between builds (scripts/README.md)."""
+"""C(32,16) seed 0 full pass, the slowest of its 8 cost-balanced shards and C(28,14) on the library named by
+LP_LIB_PATH: best and mean wall ms per pass, counts and optimum for comparison between builds (scripts/README.md)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simplexmethod_amd import capi
+from simplexmethod_amd import dist as lpdist
 ctx = capi.Context(0)
+
+
+def timed(p, lo, hi, reps):
+    p.range(lo, hi)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = p.range(lo, hi)
+        ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3, sum(ts) / len(ts) * 1e3, r
+
+
+name = os.environ.get("LP_LIB_PATH", "default")
 A, b, c, _ = capi.gen_lp(0, 16, 32)
 p = ctx.enum_problem(A, b, c, True)
-for _ in range(3):
-    r = p.range(0, p.total)
-best = 1e9
-for _ in range(10):
-    t0 = time.perf_counter()
-    r = p.range(0, p.total)
-    best = min(best, time.perf_counter() - t0)
-print("%s: full pass %.3f ms wall, kernel_ms %.3f, z=%r counts=%s" % (os.environ.get("LP_LIB_PATH", "default"), best * 1e3, r[3].kernel_ms if hasattr(r[3], "kernel_ms") else -1, r[1], r[2]), flush=True)
-from simplexmethod_amd import dist as lpdist
-worst = 0.0
-for lo, hi in [lpdist.balanced_shard_bounds(32, 16, r, 8) for r in range(8)]:
-    p.range(lo, hi)
-    bb = 1e9
-    for _ in range(8):
-        t0 = time.perf_counter()
-        p.range(lo, hi)
-        bb = min(bb, time.perf_counter() - t0)
-    worst = max(worst, bb)
-print("   slowest of the 8 cost-balanced shards %.3f ms" % (worst * 1e3), flush=True)
+for _ in range(2):
+    p.range(0, p.total)
+best, mean, r = timed(p, 0, p.total, 12)
+print("%s: C(32,16) full pass best %.3f mean %.3f ms wall, z=%r counts=%s" % (name, best, mean, r[1], r[2]), flush=True)
+worst, worst_mean = 0.0, 0.0
+for lo, hi in [lpdist.balanced_shard_bounds(32, 16, q, 8) for q in range(8)]:
+    bb, mm, _ = timed(p, lo, hi, 8)
+    worst, worst_mean = max(worst, bb), max(worst_mean, mm)
+print("   slowest of the 8 cost-balanced shards best %.3f mean %.3f ms  (full / slowest = %.2f)" % (worst, worst_mean, best / worst), flush=True)
+p.free()
+A, b, c, _ = capi.gen_lp(0, 14, 28)
+p = ctx.enum_problem(A, b, c, True)
+best, mean, r = timed(p, 0, p.total, 12)
+print("   C(28,14) full pass best %.3f mean %.3f ms wall, z=%r counts=%s" % (best, mean, r[1], r[2]), flush=True)

@@ -1,5 +1,5 @@
 """One-launch-per-pivot path with the selection overlapped (LP_SIMPLEX_ALGO_OVERLAP): us per pivot and the rate of the
-algorithmic bytes 16 * m * (n + 1) against the launch-pair path, first 300 pivots, best of 3."""
+algorithmic bytes 16 * m * (n + 1) against the launch-pair and the look-ahead path, first 300 pivots, best of 3."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simplexmethod_amd import capi
@@ -10,12 +10,18 @@ if len(sys.argv) > 1:
 for m, n in shapes:
     A, b, c, basis = capi.gen_lp(0, m, n)
     p = ctx.simplex_problem(A, b, c, basis, True, n - m)
-    for name, algo in (("overlap", capi.SIMPLEX_OVERLAP), ("launch", capi.SIMPLEX_LAUNCH)):
+    for name, algo in (("overlap", capi.SIMPLEX_OVERLAP), ("launch", capi.SIMPLEX_LAUNCH), ("lookahead", capi.SIMPLEX_LOOKAHEAD)):
         best = 1e9
         for _ in range(3):
             p.reset()
-            rc, st = p.run(algo=algo, max_iter=300)
+            try:
+                rc, st = p.run(algo=algo, max_iter=300)
+            except capi.LPError as ex:
+                print("   %s: %s" % (name, ex))
+                break
             best = min(best, st.solve_ms)
+        if best == 1e9:
+            continue
         us = 1e3 * best / max(st.pivots, 1)
         print("%5d x %5d %-8s rc=%d pivots=%4d  %8.3f us/pivot  %6.2f TB/s (%.3f of 8 TB/s)" %
               (m, n, name, rc, st.pivots, us, 16.0 * m * (n + 1) / us / 1e6, 16.0 * m * (n + 1) / us / 8e6), flush=True)

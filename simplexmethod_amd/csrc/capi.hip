@@ -373,7 +373,7 @@ int lp_simplex_run(lp_simplex_problem* p, double eps, int max_iter, int algo,
     const bool asked_auto = algo == LP_SIMPLEX_ALGO_AUTO;
     if (algo == LP_SIMPLEX_ALGO_AUTO)
         algo = p->res.G >= 1 ? LP_SIMPLEX_ALGO_RESIDENT
-               : p->look.J >= 2 ? LP_SIMPLEX_ALGO_LOOKAHEAD
+               : p->look.J >= 3 ? LP_SIMPLEX_ALGO_LOOKAHEAD   // (depth 2, 1536 x 3072: 20.0 us per pivot against the overlapped path's 18.4)
                : lp_overlap_auto(p->dev.m) ? LP_SIMPLEX_ALGO_OVERLAP : LP_SIMPLEX_ALGO_LAUNCH;
     if (algo == LP_SIMPLEX_ALGO_OVERLAP && asked_auto && lp_overlap_prepare(p) != LP_OPTIMAL) {
         (void)hipGetLastError();   // no memory for the second tableau buffer: the launch pair per pivot

@@ -408,54 +408,110 @@ __global__ __launch_bounds__(OV_TX* OV_TY) void k_simplex_overlap(SimplexDev d, 
     const double* lcol = ov.lcol[cur];
     const int je = e >> 1;
     if constexpr (LINEAR) {
-        // Few tiles for the chip (fewer than three rounds of the 2 x 256 resident workgroups: at 2048 x 4096 the 1089
-        // tiles are 2.13 rounds, the third one 13 % full — 26.6 us per launch against the 22.7 of the stand-alone
-        // kernel's 4257 small workgroups): the update workgroups are PERSISTENT and share the tableau evenly and
-        // linearly instead — workgroup w streams the contiguous piece [G w / W, G (w+1) / W) of the row-major tableau
-        // (G 16-byte column pairs), four per thread in flight; the pivot-row pair and the eta entry of each come from
-        // L1/L2 (row r and the eta column are 50 KB, hot): 24.2 us.  On larger tableaus the tiles win (a loop's
-        // iterations do not overlap: 3072 x 6144 57 us in tiles, 72 linear): the other instantiation of this kernel.
+        // Few tiles for the chip (fewer than six per CU: at 2048 x 4096 the 1089 tiles of one workgroup per CU — the
+        // kernel's registers allow no second one — are 4.25 rounds, 26.6 us per launch against the 22.7 of the
+        // stand-alone kernel's 4257 small workgroups): the update workgroups are PERSISTENT, one per CU (the launch has
+        // 256 workgroups, the selector included), and share the tableau evenly and linearly — workgroup w streams the
+        // contiguous piece [G w / W, G (w+1) / W) of the row-major tableau (G 16-byte column pairs) through a ring of
+        // eight pairs per thread; the pivot-row pair and the eta entry of each come from L1/L2 (row r and the eta column
+        // are 50 KB, hot): 23.2 us.  On larger tableaus the tiles win (2048 x 8192: 48 us in tiles, 55 linear; 3072 x
+        // 6144 57 against 69): the other instantiation of this kernel.
         const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1;
         const int T = OV_TX * OV_TY;
         const double2* P2 = S2 + (size_t)r * ld2;   // the pivot row: row r of T_{k-1}
         const long long G = (long long)rows * ld2;
         const long long g0 = G * w / W, g1 = G * (w + 1) / W;
-        for (long long gb = g0 + threadIdx.x; gb < g1; gb += (long long)T * OV_LIN) {
-            double2 t[OV_LIN], pr[OV_LIN];
-            double l[OV_LIN];
-            int ii[OV_LIN], jj[OV_LIN];
-#pragma unroll
-            for (int q = 0; q < OV_LIN; ++q) {
-                const long long g = gb + (long long)q * T;
-                ii[q] = (int)(g / ld2);
-                jj[q] = (int)(g - (long long)ii[q] * ld2);
-                if (g < g1) {
-                    t[q] = S2[g];
-                    pr[q] = P2[jj[q]];
-                    l[q] = lcol[ii[q]];
-                }
+        // A thread's elements are T apart; their row and column pair are carried (one division per thread: eight
+        // 64-bit divisions per round had been ~1 k VALU instructions per thread in a loop that otherwise has ~100).
+        // The OV_LIN slots are a RING: as soon as a slot's element is stored, the element OV_LIN further on is
+        // requested into it, and a slot is waited for with a COUNTED s_waitcnt — vmcnt returns in issue order, so
+        // "at most 28 younger operations outstanding" (seven slots x (one store + three loads)) says exactly that
+        // this slot's three loads have landed.  The compiler cannot count across the loop's branches (it waits for
+        // vmcnt(0) at the loop head: whole rounds of OV_LIN, and a share of 16.08 elements per thread — 2049 x 2049
+        // pairs on 255 workgroups — then costs THREE round trips, the third for two of the sixteen waves with the CU
+        // idle behind them), so loads, stores and waits are inline asm and every one of them is issued by every wave
+        // in every step: loads with clamped indices, stores under an exec mask rather than a branch.
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        const dbl2* Sv = reinterpret_cast<const dbl2*>(S2);
+        const dbl2* Pv = reinterpret_cast<const dbl2*>(P2);
+        dbl2* Dv = reinterpret_cast<dbl2*>(D2);
+        const int dT = T / ld2, rT = T - dT * ld2;
+        auto advance = [&](int& i, int& j) {
+            i += dT;
+            j += rT;
+            if (j >= ld2) {
+                j -= ld2;
+                ++i;
             }
-#pragma unroll
-            for (int q = 0; q < OV_LIN; ++q) {
-                const long long g = gb + (long long)q * T;
-                if (g < g1) {
-                    const int i = ii[q], jp = jj[q];
-                    double2 v = t[q];
-                    if (i == r) {
-                        v.x = pr[q].x * l[q];
-                        v.y = pr[q].y * l[q];
-                    } else {
-                        v.x = fma(l[q], pr[q].x, v.x);
-                        v.y = fma(l[q], pr[q].y, v.y);
-                    }
-                    if (jp == je) {
-                        const double unit = (i == r) ? 1.0 : 0.0;
-                        if (e & 1) v.y = unit; else v.x = unit;
-                    }
-                    D2[g] = v;
-                }
-            }
+        };
+        // (element indices fit 32 bits: the host takes this form only below 6 x 256 tiles of 8192 pairs)
+        const int gend = (int)g1, gbeg = (int)g0;
+        int g_i = gbeg + (int)threadIdx.x;   // next element to request
+        int i_i = g_i / ld2, j_i = g_i - i_i * ld2;
+        int g_c = g_i;                       // next element to finish
+        int i_c = i_i, j_c = j_i;
+        dbl2 t0, t1, t2, t3, t4, t5, t6, t7, p0, p1, p2, p3, p4, p5, p6, p7;
+        double l0, l1, l2, l3, l4, l5, l6, l7;
+        int pad_ = 0;
+        static_assert(OV_LIN == 8, "the ring below is written out for eight slots");
+#define OV_REQUEST(TQ, PQ, LQ)                                                                                        \
+    do {                                                                                                              \
+        const unsigned ot_ = (unsigned)(g_i < gend ? g_i : gbeg) << 4;   /* (past the share: one hot line) */           \
+        const unsigned op_ = (unsigned)j_i << 4;                                                                      \
+        const unsigned ol_ = (unsigned)(i_i < rows ? i_i : rows - 1) << 3;                                            \
+        asm volatile("global_load_dwordx4 %0, %3, %6\n\tglobal_load_dwordx4 %1, %4, %7\n\tglobal_load_dwordx2 %2, %5, %8" \
+                     : "=&v"(TQ), "=&v"(PQ), "=&v"(LQ)                                                                \
+                     : "v"(ot_), "v"(op_), "v"(ol_), "s"(Sv), "s"(Pv), "s"(lcol)                                      \
+                     : "memory");                                                                                     \
+        g_i += T;                                                                                                     \
+        advance(i_i, j_i);                                                                                            \
+    } while (0)
+        // (the prologue's requests carry a fourth operation each — a load of one hot word — so that the count of
+        // younger operations is 28 from the first turn of the ring on: 4 per slot, as in the loop, where it is the store)
+// (its destination stays ONE live register up to the end of the ring: a dead one would be reused while the load is in flight)
+#define OV_PAD() asm volatile("global_load_dword %0, %1, %2" : "+v"(pad_) : "v"(0u), "s"(lcol) : "memory")
+#define OV_FINISH(TQ, PQ, LQ)                                                                                         \
+    do {                                                                                                              \
+        asm volatile("s_waitcnt vmcnt(28)" : "+v"(TQ), "+v"(PQ), "+v"(LQ));                                           \
+        dbl2 v_ = TQ;                                                                                                 \
+        if (i_c == r) {                                                                                               \
+            v_.x = PQ.x * LQ;                                                                                         \
+            v_.y = PQ.y * LQ;                                                                                         \
+        } else {                                                                                                      \
+            v_.x = fma(LQ, PQ.x, v_.x);                                                                               \
+            v_.y = fma(LQ, PQ.y, v_.y);                                                                               \
+        }                                                                                                             \
+        if (j_c == je) {                                                                                              \
+            const double unit_ = (i_c == r) ? 1.0 : 0.0;                                                              \
+            if (e & 1) v_.y = unit_; else v_.x = unit_;                                                               \
+        }                                                                                                             \
+        const unsigned long long live_ = __ballot(g_c < gend);                                                        \
+        const unsigned od_ = (unsigned)(g_c < gend ? g_c : gbeg) << 4;                                                \
+        unsigned long long sv_;                                                                                       \
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, %4\n\ts_mov_b64 exec, %0" \
+                     : "=&s"(sv_)                                                                                     \
+                     : "s"(live_), "v"(od_), "v"(v_), "s"(Dv)                                                         \
+                     : "memory");                                                                                     \
+        g_c += T;                                                                                                     \
+        advance(i_c, j_c);                                                                                            \
+    } while (0)
+        OV_REQUEST(t0, p0, l0); OV_PAD(); OV_REQUEST(t1, p1, l1); OV_PAD(); OV_REQUEST(t2, p2, l2); OV_PAD();
+        OV_REQUEST(t3, p3, l3); OV_PAD(); OV_REQUEST(t4, p4, l4); OV_PAD(); OV_REQUEST(t5, p5, l5); OV_PAD();
+        OV_REQUEST(t6, p6, l6); OV_PAD(); OV_REQUEST(t7, p7, l7); OV_PAD();
+        while (g_c < gend) {
+            OV_FINISH(t0, p0, l0); OV_REQUEST(t0, p0, l0);
+            OV_FINISH(t1, p1, l1); OV_REQUEST(t1, p1, l1);
+            OV_FINISH(t2, p2, l2); OV_REQUEST(t2, p2, l2);
+            OV_FINISH(t3, p3, l3); OV_REQUEST(t3, p3, l3);
+            OV_FINISH(t4, p4, l4); OV_REQUEST(t4, p4, l4);
+            OV_FINISH(t5, p5, l5); OV_REQUEST(t5, p5, l5);
+            OV_FINISH(t6, p6, l6); OV_REQUEST(t6, p6, l6);
+            OV_FINISH(t7, p7, l7); OV_REQUEST(t7, p7, l7);
         }
+        asm volatile("" ::"v"(pad_));
+#undef OV_PAD
+#undef OV_REQUEST
+#undef OV_FINISH
         return;
     }
     // ---- one tile of 128 columns x 64 rows per workgroup
@@ -551,10 +607,18 @@ int lp_simplex_run_overlap(lp_simplex_problem* p, double eps, int max_iter, lp_s
     }
     const int nbx = lp_ceil_div(d.ld / 2, OV_TX);
     const int nby = lp_ceil_div(d.m + 1, OV_TY * OV_RPT);
-    // the update: a tile per workgroup, or — fewer than three rounds of tiles on the resident workgroups (two of 1024
-    // threads per CU) — persistent workgroups with even linear shares (see the kernel)
-    const int linear = (nbx * nby < 6 * ctx->num_cus) ? 1 : 0;
-    const unsigned grid = 1u + (unsigned)(linear ? std::max(1, std::min(nbx * nby, 2 * ctx->num_cus - 1)) : nbx * nby);
+    // the update: a tile per workgroup, or — fewer than six tiles per CU — one persistent workgroup per CU with even
+    // linear shares (see the kernel; two per CU, as the thread count would allow, do not fit its registers: the second
+    // generation of 255 short shares ran behind the first, 29 us against 23)
+#ifndef LP_OVERLAP_LINEAR_ROUNDS   // diagnostic builds: tile rounds below which the linear form is taken / its workgroups per CU
+#define LP_OVERLAP_LINEAR_ROUNDS 6
+#endif
+#ifndef LP_OVERLAP_LINEAR_WGS
+#define LP_OVERLAP_LINEAR_WGS 1
+#endif
+    const long long pairs = (long long)(d.m + 1) * (d.ld / 2);
+    const int linear = (nbx * nby < LP_OVERLAP_LINEAR_ROUNDS * ctx->num_cus && pairs < (1LL << 27)) ? 1 : 0;   // (32-bit byte offsets in the ring)
+    const unsigned grid = 1u + (unsigned)(linear ? std::max(1, std::min(nbx * nby, LP_OVERLAP_LINEAR_WGS * ctx->num_cus - 1)) : nbx * nby);
     int launches = 0;
     LP_HIP(ctx, hipEventRecord(p->ev0, s));
     hipLaunchKernelGGL(k_overlap_init, 1, 1, 0, s, d, ov, eps, max_iter);
