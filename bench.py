@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-large-shape", action="store_true",
                     help="skip the 2048x4096 leg (profiles: keeps k_simplex_update's per-launch average to the 512x1024 workload)")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes for `traffic` (the committed profile is used if its hash matches)")
     ap.add_argument("--batch", type=int, default=4096)
     return ap.parse_args()
 
@@ -73,9 +75,9 @@ def pmc_profile():
     """profiles/r04_pmc_traffic.json (written by scripts/pmc_to_json.py from separate rocprofv3 --pmc
     passes: FETCH_SIZE and WRITE_SIZE of scripts/pmc_traffic.py, the VALU and fp64 instruction counters of
     scripts/pmc_enum.py; plus the rocprofv3 --kernel-trace average of k_simplex_update): HBM bytes per
-    launch of the tableau kernels, executed fp64 operations per enumerated subset.  bench.py cannot run
-    rocprofv3 on itself, so the figures are reported only when the file was taken on exactly these
-    kernel sources; otherwise they are null."""
+    launch of the tableau kernels, executed fp64 operations per enumerated subset.  The tableau kernels' traffic is
+    measured again by every default run (live_pmc_traffic: child processes under rocprofv3 --pmc); the other
+    counters are reported only when the file was taken on exactly these kernel sources, otherwise they are null."""
     try:
         data = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
     except Exception:
@@ -84,10 +86,71 @@ def pmc_profile():
 
 
 def traffic_of(prof, kernel):
+    """HBM bytes per launch: measured by this run's own PMC passes (live_pmc_traffic) if they ran, else the
+    committed profile's figure for these kernel sources, else None."""
+    if kernel in _LIVE_PMC.get("kernels", {}):
+        return float(_LIVE_PMC["kernels"][kernel]["hbm_bytes_per_launch"])
     try:
         return float(prof["kernels"][kernel]["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
+_LIVE_PMC = {}
+_PMC_KERNELS = ("k_simplex_resident", "k_simplex_update", "k_look_update", "k_simplex_overlap")
+
+
+def live_pmc_traffic(timeout_s=150):
+    """HBM traffic of the tableau kernels measured IN THIS RUN (the line's `traffic` used to come
+    from a committed file only): two child processes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, no trace domains: MI355X_MICROARCH.md's HBM recipe) on scripts/pmc_traffic.py, before this process
+    touches the GPU; per launch (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes — rocprofv3 reports KB and FETCH_SIZE
+    reads half of a wide read on gfx950, the guide's correction.  Skipped (the committed, hash-gated profile is
+    used instead, and the line says so) when rocprofv3 is missing, when this process itself runs under a profiler,
+    or when a pass fails or times out."""
+    import collections, csv, glob, shutil, subprocess, tempfile, time
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return "skipped: this process runs under a profiler"
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return "skipped: rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="lp_pmc_")
+    t0 = time.perf_counter()
+    try:
+        per = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            r = subprocess.run([tool, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "scripts", "pmc_traffic.py")], capture_output=True, text=True,
+                               timeout=timeout_s, cwd=out)
+            files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))
+            if r.returncode != 0 or not files:
+                return "skipped: rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for row in csv.DictReader(open(files[-1])):
+                if row["Counter_Name"] != counter:
+                    continue
+                for k in _PMC_KERNELS:
+                    if k in row["Kernel_Name"]:
+                        acc[k][0] += float(row["Counter_Value"])
+                        acc[k][1] += 1
+            per[counter] = {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+        kernels = {}
+        for k in _PMC_KERNELS:
+            if k in per["FETCH_SIZE"] and k in per["WRITE_SIZE"]:
+                f, w = per["FETCH_SIZE"][k], per["WRITE_SIZE"][k]
+                kernels[k] = {"FETCH_SIZE_KB": round(f[0], 2), "WRITE_SIZE_KB": round(w[0], 2), "launches_sampled": [f[1], w[1]],
+                              "hbm_bytes_per_launch": round((2.0 * f[0] + w[0]) * 1024.0, 1)}
+        if not kernels:
+            return "skipped: no kernel of the workload in the counter files"
+        _LIVE_PMC["kernels"] = kernels
+        return "measured in this run: rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, on scripts/pmc_traffic.py (%.0f s)" % (time.perf_counter() - t0)
+    except subprocess.TimeoutExpired:
+        return "skipped: a rocprofv3 --pmc pass exceeded %d s" % timeout_s
+    except Exception as ex:   # never let the profiler cost the bench its line
+        return "skipped: %s" % (str(ex)[:120],)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def pivot_leg(ctx, args):
@@ -526,6 +589,11 @@ def main():
                      "(one process per GPU)")
         args.gpus = world
 
+    # `traffic` of the tableau kernels: measured by two child processes before this one touches the GPU (N = 1 only)
+    pmc_source = None
+    if rank == 0 and world == 1 and not args.no_pivot and not args.no_live_pmc and (args.pivot_m, args.pivot_n) == (512, 1024):
+        pmc_source = live_pmc_traffic()
+
     import torch
     from simplexmethod_amd import capi
     from simplexmethod_amd import dist as lpdist
@@ -671,6 +739,9 @@ def main():
     if rank == 0 and not args.no_pivot:
         pivot, roofline, roofline_whole, roofline_rank1, rankj = pivot_leg(ctx, args)
         line["pivot"] = pivot
+        roofline["traffic_source"] = (pmc_source if _LIVE_PMC else
+                                      ("committed profile profiles/%s (taken on these kernel sources)" % PMC_PROFILE if prof_all else "none")
+                                      + ("" if pmc_source is None else "; live passes " + pmc_source))
         line["roofline"] = roofline
         line["roofline_whole_pivot"] = roofline_whole
         line["roofline_rank1_update"] = roofline_rank1
