@@ -125,6 +125,13 @@ def load():
             raise RuntimeError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        if path == _build.HIP_LIB:   # a library older than its sources measures and tests something else
+            srcs = [os.path.join(_build.CSRC, f) for f in os.listdir(_build.CSRC) if f.endswith((".hip", ".hpp"))]
+            stale = [os.path.basename(f) for f in srcs if os.path.getmtime(f) > os.path.getmtime(path) + 1.0]
+            if stale:
+                import sys
+                print(f"simplexmethod_amd: {os.path.basename(path)} is OLDER than {', '.join(sorted(stale))} - rebuild "
+                      "(python -c 'import __graft_entry__ as g; g.build()')", file=sys.stderr)
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError = ABI symbol missing

@@ -95,6 +95,7 @@ void lp_context_destroy(lp_context* ctx) {
     }
     (void)hipFree(ctx->dcomb6);
     (void)hipFree(ctx->dcomb5);
+    (void)hipFree(ctx->dcomb4);
     for (hipStream_t a : ctx->aux_stream)
         if (a) (void)hipStreamDestroy(a);
     for (hipEvent_t e : ctx->aux_event)
@@ -852,7 +853,7 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
         LP_TRY(hipMalloc(&pd.root_cursor, 2 * sizeof(int)));
         LP_TRY(enum_list_alloc(p, want_cap));
         pd.list_count = &p->d_pass->list_count;
-        if (!ctx->dcomb6 || !ctx->dcomb5) {   // (shape-independent: once per context)
+        if (!ctx->dcomb6 || !ctx->dcomb5 || !ctx->dcomb4) {   // (shape-independent: once per context)
             // leaf kernel: every 6-subset of R <= 22 columns in lexicographic order, 5 bits per index
             std::vector<unsigned> comb6(32, 0u);
             for (int R = 6; R <= 22; ++R) {
@@ -889,10 +890,29 @@ int lp_enum_upload(lp_context* ctx, const double* A, int m, int n, const double*
             }
             LP_TRY(hipMalloc(&ctx->dcomb5, sizeof(unsigned) * comb5.size()));
             LP_TRY(hipMemcpyAsync(ctx->dcomb5, comb5.data(), sizeof(unsigned) * comb5.size(), hipMemcpyHostToDevice, s));
-            LP_TRY(hipStreamSynchronize(s));  // comb6 / comb5 are locals
+            // third level: every 4-subset of R <= 20 columns
+            std::vector<unsigned> comb4(32, 0u);
+            for (int R = 4; R <= 20; ++R) {
+                comb4[(size_t)R] = (unsigned)comb4.size();
+                int s4[4] = {0, 1, 2, 3};
+                for (;;) {
+                    unsigned pk = 0;
+                    for (int t = 0; t < 4; ++t) pk |= (unsigned)s4[t] << (5 * t);
+                    comb4.push_back(pk);
+                    int t = 3;
+                    while (t >= 0 && s4[t] == R - 4 + t) --t;
+                    if (t < 0) break;
+                    ++s4[t];
+                    for (int u = t + 1; u < 4; ++u) s4[u] = s4[u - 1] + 1;
+                }
+            }
+            LP_TRY(hipMalloc(&ctx->dcomb4, sizeof(unsigned) * comb4.size()));
+            LP_TRY(hipMemcpyAsync(ctx->dcomb4, comb4.data(), sizeof(unsigned) * comb4.size(), hipMemcpyHostToDevice, s));
+            LP_TRY(hipStreamSynchronize(s));  // comb6 / comb5 / comb4 are locals
         }
         pd.comb6 = ctx->dcomb6;
         pd.comb5 = ctx->dcomb5;
+        pd.comb4 = ctx->dcomb4;
     }
     LP_TRY(hipStreamSynchronize(s));
 #undef LP_TRY

@@ -16,7 +16,7 @@
 // abundance (the cooperative sweep of enum_prefix.hip shares two more levels but is bound by the
 // latency of its broadcasts, pivot searches and workgroup barriers).
 //
-// k_enum_leaves<2> (two thirds of the subsets).  The subsets below a child are grouped by their
+// k_enum_leaves<2> / <3> (two thirds of the subsets; <3> adds a third shared pivot for the large sub-groups, see MODE 3).  The subsets below a child are grouped by their
 // first remaining column; a group that leaves >= kGrandMin selectable columns gets a second
 // in-LDS pivot and its lanes take 5 columns each (items of table 1).  k_enum_leaves<1> finishes
 // what is left of each child (items of table 0).
@@ -48,6 +48,11 @@ constexpr int LEAF_WAVES = LEAF_THREADS / 64;
 #endif
 constexpr int kGrandMin = LP_GRAND_MIN;         // a depth m-5 node with >= 10 selectable columns (>= 252 subsets) is
                                       // finished by the two-level kernel (second in-LDS pivot, 5 columns per lane)
+#ifndef LP_GREAT_MIN
+#define LP_GREAT_MIN 9
+#endif
+constexpr int kGreatMin = LP_GREAT_MIN;         // k_enum_leaves<3>: a sub-group (child, j2, j3) that leaves >= 9 selectable
+                                      // columns (>= 126 subsets) gets a third in-LDS pivot, 4 columns per lane
 constexpr int THIN_TAIL = 8;          // the thin kernel takes the subsets inside the last 8 columns
 constexpr int TS = PG + 1;            // LDS column stride (doubles): odd, so that lanes reading the
                                       // same row of different columns hit different banks
@@ -384,7 +389,7 @@ constexpr int kItemLanesWide = 4, kItemLanesNarrow = 8;
 // one atomic per wave and table.  FUSED: records are depth m-7 nodes; for each child a (with at
 // least min_child_R selectable columns; the thin kernel takes the rest) whose subsets meet
 // [begin, end):
-//   table 1 (k_enum_leaves<2>): the child's subsets are grouped by their first remaining column
+//   table 1 (k_enum_leaves<3>): the child's subsets are grouped by their first remaining column
 //     j2 (lexicographic order); every group that leaves at least kGrandMin selectable columns is
 //     cut into items (record, a | j2 << 8 | groups << 16, first subset of the chunk inside the
 //     group, rank offset of the group inside the record) — a large group in chunks of kChunk, or
@@ -577,6 +582,13 @@ __global__ __launch_bounds__(1024) void k_enum_make_items(EnumDev d, PrefixDev p
 //         step, which costs a lane a third of its instructions.  A kernel of its own so that the
 //         register allocation of MODE 1's loop is not disturbed (the two loops in one kernel cost
 //         that loop 12 %).
+// MODE 3: MODE 2's items; inside a group the subsets are in lexicographic order again, so those that share their
+//         first remaining column j3 are consecutive — C(R2 - 1 - j3, 4) of them.  Every such sub-group that leaves
+//         >= kGreatMin selectable columns (half of all subsets of C(32,16)) gets a THIRD in-LDS pivot and its lanes
+//         take 4 columns each (two Gauss-Jordan steps whose rows are chosen before they are loaded, no register
+//         rotation at all, then the 2x2 block: ~200 instructions per subset against ~320 with 5 columns); what is
+//         left of the group is finished with 5 columns as in MODE 2.  The great-grandchild tableau lives in the
+//         half of the record's double buffer that the NEXT item's record will be written to (free until then).
 // MODE 0 (m = 6): the root record is the depth m-6 node.
 template <int MODE, bool EXACT>
 __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
@@ -589,24 +601,29 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     __shared__ __attribute__((aligned(16))) double s_tab[LEAF_WAVES * 2][MAXCOLS * TS];  // double-buffered
     __shared__ __attribute__((aligned(16))) double s_child[FUSED ? LEAF_WAVES : 1][FUSED ? CHILDCOLS * TS : 1];
     __shared__ __attribute__((aligned(16))) double s_child2[MODE == 1 ? LEAF_WAVES : 1][MODE == 1 ? CHILDCOLS * TS : 1];
-    __shared__ __attribute__((aligned(16))) double s_grand[MODE == 2 ? LEAF_WAVES : 1][MODE == 2 ? (NMX + KD) * TS : 1];
+    __shared__ __attribute__((aligned(16))) double s_grand[MODE >= 2 ? LEAF_WAVES : 1][MODE >= 2 ? (NMX + KD) * TS : 1];
     __shared__ unsigned int s_binom[(NMX + KD + 2) * (KD + 1)];  // C(r, k), r <= NMX+KD+1, k <= KD
     __shared__ unsigned long long s_cnt[3];
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
-    __shared__ unsigned int s_rows[36];  // leaf_row_table of this kernel's lanes (5 columns each in MODE 2, else 6)
+    __shared__ unsigned int s_rows[36];  // leaf_row_table of this kernel's lanes (5 columns each in MODE 2 / 3, else 6)
+    __shared__ unsigned int s_off4[MODE == 3 ? 32 : 1], s_rows4[MODE == 3 ? 16 : 1];   // MODE 3: the same for 4 columns
 
     const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
-    const int4* const items = MODE == 2 ? pd.items2 : pd.items;   // built by k_enum_make_items
-    const int nitems = MODE == 2 ? min(pd.item_count[1], pd.item_cap2) : min(pd.item_count[0], pd.item_cap);
-    int* const cursor = pd.root_cursor + (MODE == 2 ? 1 : 0);
+    const int4* const items = MODE >= 2 ? pd.items2 : pd.items;   // built by k_enum_make_items
+    const int nitems = MODE >= 2 ? min(pd.item_count[1], pd.item_cap2) : min(pd.item_count[0], pd.item_cap);
+    int* const cursor = pd.root_cursor + (MODE >= 2 ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
     }
     if (tid < 3) s_cnt[tid] = 0ULL;
-    if (tid < 32) s_off[tid] = MODE == 2 ? pd.comb5[tid] : pd.comb6[tid];
-    leaf_row_table<(MODE == 2 ? 5 : 6)>(s_rows, tid);
+    if (tid < 32) s_off[tid] = MODE >= 2 ? pd.comb5[tid] : pd.comb6[tid];
+    leaf_row_table<(MODE >= 2 ? 5 : 6)>(s_rows, tid);
+    if constexpr (MODE == 3) {
+        if (tid < 32) s_off4[tid] = pd.comb4[tid];
+        leaf_row_table<4>(s_rows4, tid);
+    }
     __syncthreads();
     unsigned int cntF = 0, cntI = 0, cntS = 0;
     unsigned int viol = 0;   // !EXACT: a pivot left the fast reciprocal's range (leaf_verdict)
@@ -693,7 +710,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
         const unsigned int L = s_binom[R * (KD + 1) + KD];   // (MODE 0/1)
         // subset table: all 6-subsets of R columns in lexicographic order, 5 bits per index
         // (one L2-resident load; a dependent unranking loop over binomials costs ~2k cycles)
-        const unsigned* comb = pd.comb6 + s_off[MODE == 2 ? 0 : R];
+        const unsigned* comb = pd.comb6 + s_off[MODE >= 2 ? 0 : R];
         unsigned long long rb = pm.rank_base + (unsigned long long)(FUSED ? roff : 0);
         const unsigned int leaf_lo = (unsigned int)chunk;
         const unsigned int leaf_hi = (leaf_lo + kChunk < L) ? leaf_lo + kChunk : L;
@@ -714,7 +731,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             if (!(big > 0.0) || minp0 <= DBL_EPSILON * (double)m * maxp0) {
                 // every subset below this node is singular
                 unsigned int span = leaf_hi - leaf_lo;
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     span = 0;
                     for (int gi = 0; gi < ngroups; ++gi) span += s_binom[(R - 1 - j2_first - gi) * (KD + 1) + KD - 1];
                     if (ngroups == 1) span = min(span - leaf_lo, (unsigned int)kChunk);
@@ -754,7 +771,7 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             tab += (last + 1 - D) * TS;              // column q below = column last+1+q
             // (m = 6: the root record, no row used yet — the identity is the permuted order)
         }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE >= 2) {
             constexpr int K5 = KD - 1;
             const double minp1 = minp0, maxp1 = maxp0;
             for (int gi = 0; gi < ngroups; ++gi) {
@@ -794,7 +811,68 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
             }
             const unsigned* comb5 = pd.comb5 + s_off[R2];
             const int U5[K5] = {0, 1, 2, 3, 4};        // unused by leaf_verdict<PERM>
-            for (unsigned int leaf = lo2 + lane; leaf < hi2; leaf += 64) {
+            unsigned int tail_lo = lo2;                // MODE 3: the leaves in front of it went to sub-groups
+            if constexpr (MODE == 3) {
+                constexpr int K4 = KD - 2;
+                double* ggtab = s_tab[wave * 2 + buf];  // (the next item's slice: written at the top of the next iteration)
+                unsigned int off3 = 0;                  // first leaf of sub-group j3 inside the group
+                for (int j3 = 0; R2 - 1 - j3 >= kGreatMin && off3 < hi2; ++j3) {
+                    const int R3 = R2 - 1 - j3;         // selectable columns of the depth m-4 node
+                    const unsigned int L3 = s_binom[R3 * (KD + 1) + K4];
+                    const unsigned int a3 = off3 > lo2 ? off3 : lo2, b3 = off3 + L3 < hi2 ? off3 + L3 : hi2;
+                    const unsigned int base3 = off3;
+                    off3 += L3;
+                    tail_lo = off3 > lo2 ? off3 : lo2;
+                    if (a3 >= b3 || overlap(rb2 + a3, b3 - a3, begin, end) == 0ULL) continue;
+                    // ---- third pivot, on column j3 of the grandchild tableau (unused rows at positions 0..4, ascending)
+                    const double* pcol3 = gtab + j3 * TS;
+                    const double w3 = pcol3[r];
+                    double big3;
+                    const int p3 = __builtin_amdgcn_readfirstlane(pick_pivot_row(w3, r >= K5, lane & ~(PG - 1), big3));
+                    const double minp3 = fmin(minp2, big3), maxp3 = fmax(maxp2, big3);
+                    if (!(big3 > 0.0) || minp3 <= DBL_EPSILON * (double)m * maxp3) {
+                        if (lane == 0) cntS += (unsigned int)overlap(rb2 + a3, b3 - a3, begin, end);
+                        continue;
+                    }
+                    const double inv3 = 1.0 / pcol3[p3];
+                    const bool isp3 = (r == p3);
+                    const double lx3 = isp3 ? inv3 : -(w3 * inv3);
+                    // rows: the 4 unused ones at 0..3, the new pivot row at 4, the rest stay
+                    const int pos3 = (r < p3) ? r : (r == p3) ? K4 : (r < K5) ? r - 1 : r;
+#pragma unroll
+                    for (int q = 0; q < (NMX + KD + 2) / 4; ++q) {
+                        const int j = g + 4 * q;        // column j = grandchild column j3+1+j (j = R3: rhs)
+                        if (j <= R3) {
+                            const double* pc = gtab + (j3 + 1 + j) * TS;
+                            ggtab[j * TS + pos3] = fma(lx3, pc[p3], isp3 ? -0.0 : pc[r]);
+                        }
+                    }
+                    const unsigned* comb4 = pd.comb4 + s_off4[R3];
+                    const int U4[K4] = {0, 1, 2, 3};    // unused by leaf_verdict<PERM>
+                    for (unsigned int leaf = a3 + lane; leaf < b3; leaf += 64) {
+                        const unsigned long long rank = rb2 + leaf;
+                        if (rank < begin || rank >= end) continue;
+                        int c4[K4];
+                        const unsigned pk = comb4[leaf - base3];
+#pragma unroll
+                        for (int t = 0; t < K4; ++t) c4[t] = (int)((pk >> (5 * t)) & 31u);
+                        const int verdict = leaf_verdict<K4, TS, true, false, !EXACT, true>(ggtab, c4, R3, U4, 0u, minp3, maxp3, m, nullptr, &viol, s_rows4);
+                        if (verdict == 2) {
+                            ++cntS;
+                        } else if (verdict == 1) {
+                            ++cntI;
+                        } else {
+                            ++cntF;
+                            const unsigned long long at = atomicAdd(pd.list_count, 1ULL);
+                            if (at < pd.list_cap) {
+                                pd.list[at] = rank;
+                                pd.list_rec[at] = rec;
+                            }
+                        }
+                    }
+                }
+            }
+            for (unsigned int leaf = tail_lo + lane; leaf < hi2; leaf += 64) {
                 const unsigned long long rank = rb2 + leaf;
                 if (rank < begin || rank >= end) continue;
                 int c[K5];
@@ -1405,11 +1483,14 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         // single passes — C(28,14) 1.17 against 1.19 ms, C(32,16) 13.2 against 13.3 — but half of the passes then take
         // 14.0-14.1 ms: the average is worse.)
         const int grid2 = grid6, grid1 = grid6;
+#ifndef LP_LEAF_LEVELS   // diagnostic builds: 2 = table 1's kernel without the third in-LDS pivot
+#define LP_LEAF_LEVELS 3
+#endif
         if (exact) {
-            hipLaunchKernelGGL((k_enum_leaves<2, true>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<LP_LEAF_LEVELS, true>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, true>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         } else {
-            hipLaunchKernelGGL((k_enum_leaves<2, false>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
+            hipLaunchKernelGGL((k_enum_leaves<LP_LEAF_LEVELS, false>), grid2, LEAF_THREADS, 0, s, p->dev, pd, roots, b, e);
             hipLaunchKernelGGL((k_enum_leaves<1, false>), grid1, LEAF_THREADS, 0, s1, p->dev, pd, roots, b, e);
         }
         LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], sT));

@@ -78,6 +78,7 @@ struct PrefixDev {
     int4* items2;                     // table 1 (two-level kernel): (record, child | j2 << 8, first subset, rank offset)
     int* item_count;                  // [2]
     int item_cap, item_cap2;
+    const unsigned* comb4;            // same for 4-subsets (third level of the leaf kernel)
     const unsigned* comb5;            // same for 5-subsets (second level of the leaf kernel)
     const unsigned* comb6;            // [32 offsets][entries]: all 6-subsets of R columns in lex order,
                                       // 5 bits per index; entry of leaf l of R columns = comb6[comb6[R] + l]

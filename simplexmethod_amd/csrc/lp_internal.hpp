@@ -25,6 +25,7 @@ struct lp_context {
     // shape-independent subset tables of the enumeration's leaf kernels, built once per context
     unsigned* dcomb6 = nullptr;
     unsigned* dcomb5 = nullptr;
+    unsigned* dcomb4 = nullptr;
     // two more streams + events (created on first use): the enumeration's independent leaf kernels run
     // side by side so that one kernel's tail is filled by the next one's head
     hipStream_t aux_stream[2] = {nullptr, nullptr};
