@@ -378,6 +378,31 @@ __device__ __forceinline__ int leaf_verdict(const double* tab, const int (&c)[KD
     return v;
 }
 
+#ifdef LP_LEAF_WAVELOG
+// Diagnostic build (scripts/leaf_wavelog.py): every wave of the leaf kernels leaves {kernel, hardware id, start,
+// first item, end (100 MHz clock), items, steals}; read back through lp_debug_leaf_wavelog.
+constexpr int kWaveLogCap = 1 << 16;
+__device__ unsigned long long g_wavelog[kWaveLogCap][6];
+__device__ unsigned int g_wavelog_n;
+__device__ __forceinline__ void wavelog_put(int kernel, unsigned long long t0, unsigned long long t1, unsigned int items,
+                                            unsigned int steals) {
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int k = atomicAdd(&g_wavelog_n, 1u);
+        if (k < (unsigned)kWaveLogCap) {
+            unsigned int hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_wavelog[k][0] = (unsigned long long)kernel | ((unsigned long long)blockIdx.x << 8);
+            g_wavelog[k][1] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            g_wavelog[k][2] = t0;
+            g_wavelog[k][3] = t1;
+            g_wavelog[k][4] = __builtin_amdgcn_s_memrealtime();
+            g_wavelog[k][5] = (unsigned long long)items | ((unsigned long long)steals << 32);
+        }
+    }
+}
+#endif
+
 constexpr int kChunk = 1024;  // subsets per work item (16 wave passes)
 // lanes of k_enum_make_items that share one record: 4 on wide levels, 8 on the narrow ones of a small
 // rank range (there the kernel's run time is the length of one lane's loop)
@@ -607,12 +632,19 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     __shared__ unsigned int s_off[32];  // offsets of the per-R subset tables inside pd.comb6
     __shared__ unsigned int s_rows[36];  // leaf_row_table of this kernel's lanes (5 columns each in MODE 2 / 3, else 6)
     __shared__ unsigned int s_off4[MODE == 3 ? 32 : 1], s_rows4[MODE == 3 ? 16 : 1];   // MODE 3: the same for 4 columns
+    __shared__ unsigned long long s_run[LEAF_WAVES];   // every wave's run of work items {next, end}: see draw() below
+    __shared__ int s_dry;                              // a wave of this workgroup has seen the end of the item table
 
     const int m = d.m, n = d.n, D = m - KD - (FUSED ? 1 : 0);   // depth of the records
     const int4* const items = MODE >= 2 ? pd.items2 : pd.items;   // built by k_enum_make_items
     const int nitems = MODE >= 2 ? min(pd.item_count[1], pd.item_cap2) : min(pd.item_count[0], pd.item_cap);
     int* const cursor = pd.root_cursor + (MODE >= 2 ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef LP_LEAF_WAVELOG
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wl_t1 = 0;
+    unsigned int wl_items = 0, wl_steals = 0;
+#endif
     for (int k = tid; k < (NMX + KD + 2) * (KD + 1); k += LEAF_THREADS) {
         const int r = k / (KD + 1), kk = k - r * (KD + 1);
         s_binom[k] = (unsigned int)d.binom[r * kBinomK + kk];
@@ -634,21 +666,52 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     // record sits between two items.
     constexpr int NLOAD = (MAXCOLS * PG + 63) / 64;   // doubles per lane to hold one record
     const int rec_cols = n - D + 1;                   // columns of a record incl. rhs
-    // Items are dealt in runs: one returning atomic on a single word costs ~11 ns chip-wide, which
-    // at one draw per item could bound the whole kernel.  The first deal is static — wave w owns
-    // items [w*k0, (w+1)*k0) — so that the launch does not open with two atomics per wave on that
-    // word (~0.2 ms for a full grid); later runs shrink with what is left (guided self-scheduling:
-    // a wave holding a long run while the others have finished is the kernel's tail), and a wave
-    // whose last run reached the end of the table does not ask again.
-    constexpr int kMaxRun = 4;
+    // Items are dealt in runs of kRun: one returning atomic on a single word costs ~11 ns chip-wide, which at one
+    // draw per item bounds the kernel.  The first deal is static — wave w owns items [w*k0, (w+1)*k0) — so that
+    // the launch does not open with two atomics per wave on that word (~0.2 ms for a full grid).
+    // A wave's run lives in LDS as one 64-bit word {next item, end of the run}, and items leave it by compare-and-
+    // swap: when the table is dealt out, a wave that has nothing left takes items out of the runs of the other
+    // waves of its workgroup (a workgroup's wave slots and LDS are free for the next kernel's blocks only when its
+    // LAST wave ends).  That is what lets the runs stay at kRun to the end: rounds 1-3 shrank them with what was
+    // left (guided self-scheduling), and the last ~4 items per wave were then drawn one by one — 12 k single draws
+    // and 3 k failing ones queued on the one word at the end of each leaf kernel, ~0.1 ms of every pass whatever
+    // its size (scripts/leaf_wavelog.py: on an 8-way shard of C(32,16) the waves of k_enum_leaves<1> lived 9 %
+    // longer per item than on the whole range).  A wave that sees the end of the table tells its siblings.
+    constexpr int kRun = 4;
     const int nwaves = (int)gridDim.x * LEAF_WAVES;
-    const int k0 = max(1, min(kMaxRun, nitems / (nwaves * 4)));
+    const int k0 = max(1, min(kRun, nitems / (nwaves * 4)));
     const int dyn_base = nwaves * k0;
-    int draw_next = ((int)blockIdx.x * LEAF_WAVES + wave) * k0, draw_end = draw_next + k0;
-    int seen = dyn_base;   // lower bound of the cursor position
+    auto pack_run = [](int next, int end) { return ((unsigned long long)(unsigned)next << 32) | (unsigned)end; };
+    {
+        const int first = ((int)blockIdx.x * LEAF_WAVES + wave) * k0;
+        if (lane == 0) s_run[wave] = pack_run(min(first, nitems), min(first + k0, nitems));
+        if (tid == 0) s_dry = 0;
+    }
+    __syncthreads();
+    auto take = [&](int w) {   // the next item of wave w's run, -1 if it is empty
+        int item = -1;
+        if (lane == 0) {
+            unsigned long long cur = __hip_atomic_load(&s_run[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while ((unsigned)(cur >> 32) < (unsigned)cur) {
+                if (__hip_atomic_compare_exchange_strong(&s_run[w], &cur, cur + (1ULL << 32), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    item = (int)(cur >> 32);
+                    break;
+                }
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(item);
+    };
+    bool dry = dyn_base >= nitems;   // the table is dealt out
+    bool none = false;               // this wave has been told "nothing left" (final: the loop below ends on the first
+                                     // such answer, so a later, luckier draw — a sibling's last run arriving — would be lost)
     auto draw = [&]() {
-        if (draw_next == draw_end && draw_end < nitems) {
-            const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
+        if (none) return nitems;
+        int item = take(wave);
+        if (item >= 0) return item;
+        if (!dry && __hip_atomic_load(&s_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) dry = true;
+        if (!dry) {
+            constexpr int k = kRun;
             int v = 0, over = 0;
             if (lane == 0) {
                 v = atomicAdd(cursor, k);
@@ -656,12 +719,26 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
                 // whatever else this pass finds, so the waves stop drawing (the load rides with the atomic)
                 over = __hip_atomic_load(pd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pd.list_abort;
             }
-            draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
-            if (__builtin_amdgcn_readfirstlane(over)) draw_next = nitems;
-            draw_end = draw_next + k;
-            seen = draw_end;
+            v = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            if (__builtin_amdgcn_readfirstlane(over)) v = nitems;
+            if (v < nitems) {
+                if (k > 1 && lane == 0)
+                    __hip_atomic_store(&s_run[wave], pack_run(v + 1, min(v + k, nitems)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                return v;
+            }
+            dry = true;
+            if (lane == 0) __hip_atomic_store(&s_dry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return draw_next++;
+        for (int q = 1; q < LEAF_WAVES; ++q) {
+            item = take((wave + q) & (LEAF_WAVES - 1));
+#ifdef LP_LEAF_WAVELOG
+            if (item >= 0) ++wl_steals;
+#endif
+            if (item >= 0) return item;
+        }
+        none = true;
+        return nitems;
     };
     double pre[NLOAD];
     NodeMeta pmB;
@@ -686,6 +763,10 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
     int buf = 0;
     for (;;) {
         if (itemB >= nitems) break;
+#ifdef LP_LEAF_WAVELOG
+        if (!wl_items) wl_t1 = __builtin_amdgcn_s_memrealtime();
+        ++wl_items;
+#endif
         // ---- item B becomes the current item: registers -> LDS slice (odd column stride)
         const int chunk = chunkB, child = childB, roff = roffB, rec = recB;
         const NodeMeta pm = pmB;
@@ -998,6 +1079,9 @@ void k_enum_leaves(EnumDev d, PrefixDev pd, const double* __restrict__ roots, un
         }
         }
     }
+#ifdef LP_LEAF_WAVELOG
+    wavelog_put(MODE, wl_t0, wl_t1, wl_items, wl_steals);
+#endif
     if (cntF) atomicAdd(&s_cnt[0], (unsigned long long)cntF);
     if (cntI) atomicAdd(&s_cnt[1], (unsigned long long)cntI);
     if (cntS) atomicAdd(&s_cnt[2], (unsigned long long)cntS);
@@ -1020,6 +1104,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     const int m = d.m, n = d.n, D = m - KD;
     const int nrec = min(pd.level_counts[root_level], root_cap);
     const int tid = threadIdx.x;
+#ifdef LP_LEAF_WAVELOG
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid < 3) s_cnt[tid] = 0ULL;
     __syncthreads();
     // grid-stride over (record, tail subset) pairs: the grid is sized to the chip, and the three
@@ -1071,6 +1158,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_enum_thin(EnumDev d, PrefixDev
     cnt[1] += verdict == 1;
     cnt[2] += verdict == 2;
     }
+#ifdef LP_LEAF_WAVELOG
+    wavelog_put(7, wl_t0, wl_t0, 0, 0);
+#endif
     // counts: wave reduction, one LDS atomic per wave and verdict
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -1540,3 +1630,18 @@ int lp_enum_debug_reciprocal(lp_context* ctx, const double* x, int n, double* fa
     LP_HIP(ctx, e);
     return LP_OPTIMAL;
 }
+
+#ifdef LP_LEAF_WAVELOG
+// Diagnostic builds only (-DLP_LEAF_WAVELOG, scripts/leaf_wavelog.py): copies the wave log out (6 words per wave),
+// returns the number of entries and empties the log.
+extern "C" int lp_debug_leaf_wavelog(unsigned long long* out, int cap) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wavelog_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > (unsigned)kWaveLogCap) n = kWaveLogCap;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavelog), sizeof(unsigned long long) * 6 * n) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wavelog_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
