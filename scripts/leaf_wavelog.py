@@ -55,3 +55,4 @@ if s3.any():
     spread = np.array([max(v) - min(v) for v in ends.values()])
     lastm = np.array([max(v) - np.mean(v) for v in ends.values()])
     print("<3> per workgroup: spread of its waves' ends", q(spread), "; last - mean", q(lastm))
+p.free()

@@ -1242,6 +1242,8 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
     __shared__ double s_rec[LEAF_WAVES][GCOLS * TSG];
     __shared__ double s_cost[DENSE ? kEnumMaxN : 1];
     __shared__ unsigned long long s_best;
+    __shared__ unsigned long long s_run[LEAF_WAVES];   // every wave's run of work items {next, end}
+    __shared__ int s_dry;                              // a wave of this workgroup has seen the end of the item table
     double best = -INFINITY;
     const int m = d.m, n = d.n, D = m - KD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1261,30 +1263,67 @@ __global__ __launch_bounds__(LEAF_THREADS) __attribute__((amdgpu_waves_per_eu(3)
     const int U[KD] = {0, 1, 2, 3, 4, 5, 6};   // unused by leaf_verdict<PERM>
     // Items are dealt in runs (a returning atomic on one word costs ~11 ns chip-wide: at one draw per
     // item, the 1.4 M mostly tiny items of C(30,18) took 15.6 ms whatever the lanes did): a static first
-    // deal, then runs that shrink with what is left (as k_enum_leaves); a run holds ~1024 subsets on
-    // average at most (16 items of tiny records, one full item), so that runs do not become the tail
+    // deal, then runs of a fixed length — ~1024 subsets on average at most (16 items of tiny records, one full
+    // item) — held in LDS and emptied by compare-and-swap, so that a wave that finds the table dealt out takes
+    // what the other waves of its workgroup still hold (as k_enum_leaves: runs that shrank towards the end of
+    // the table made the last thousands of draws queue on the one word)
     const int kMaxRun = (int)max(1ULL, min(16ULL, 1024ULL * (unsigned long long)max(nitems, 1) / max(range_subsets, 1ULL)));
     const int nwaves = (int)gridDim.x * LEAF_WAVES;
     const int k0 = max(1, min(kMaxRun, nitems / (nwaves * 4)));
     const int dyn_base = nwaves * k0;
-    int draw_next = ((int)blockIdx.x * LEAF_WAVES + wave) * k0, draw_end = draw_next + k0;
-    int seen = dyn_base;
-    for (;;) {
-        if (draw_next == draw_end) {
-            if (draw_end >= nitems) break;
-            const int k = max(1, min(kMaxRun, (nitems - seen) / (nwaves * 2)));
+    auto pack_run = [](int next, int end) { return ((unsigned long long)(unsigned)next << 32) | (unsigned)end; };
+    {
+        const int first = ((int)blockIdx.x * LEAF_WAVES + wave) * k0;
+        if (lane == 0) s_run[wave] = pack_run(min(first, nitems), min(first + k0, nitems));
+        if (tid == 0) s_dry = 0;
+    }
+    __syncthreads();
+    auto take = [&](int w) {   // the next item of wave w's run, -1 if it is empty
+        int item = -1;
+        if (lane == 0) {
+            unsigned long long cur = __hip_atomic_load(&s_run[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while ((unsigned)(cur >> 32) < (unsigned)cur) {
+                if (__hip_atomic_compare_exchange_strong(&s_run[w], &cur, cur + (1ULL << 32), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    item = (int)(cur >> 32);
+                    break;
+                }
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(item);
+    };
+    bool dry = dyn_base >= nitems;   // the table is dealt out
+    auto draw = [&]() {
+        int item = take(wave);
+        if (item >= 0) return item;
+        if (!dry && __hip_atomic_load(&s_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) dry = true;
+        if (!dry) {
+            const int k = kMaxRun;
             int v = 0, over = 0;
             if (lane == 0) {
                 v = atomicAdd(&pd.root_cursor[0], k);
                 if (!DENSE)   // (a list far beyond its capacity: the caller switches to the dense form)
                     over = __hip_atomic_load(pd.list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pd.list_abort;
             }
-            draw_next = __builtin_amdgcn_readfirstlane(v) + dyn_base;
-            if (__builtin_amdgcn_readfirstlane(over)) draw_next = nitems;
-            draw_end = draw_next + k;
-            seen = draw_end;
+            v = __builtin_amdgcn_readfirstlane(v) + dyn_base;
+            if (__builtin_amdgcn_readfirstlane(over)) v = nitems;
+            if (v < nitems) {
+                if (k > 1 && lane == 0)
+                    __hip_atomic_store(&s_run[wave], pack_run(v + 1, min(v + k, nitems)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                return v;
+            }
+            dry = true;
+            if (lane == 0) __hip_atomic_store(&s_dry, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const int item = draw_next++;
+        for (int q = 1; q < LEAF_WAVES; ++q) {
+            item = take((wave + q) & (LEAF_WAVES - 1));
+            if (item >= 0) return item;
+        }
+        return nitems;
+    };
+    for (;;) {
+        const int item = draw();
         if (item >= nitems) break;
         const int4 it = pd.items[item];
         const int rec = __builtin_amdgcn_readfirstlane(it.x);
