@@ -832,3 +832,24 @@ def test_prefix_level_kernels_agree(ctx, m, n, seed, monkeypatch):
             assert p.first_within(lo, hi, ref[1]) == k
         monkeypatch.delenv(var)
     p.free()
+
+
+@pytest.mark.parametrize("m,n,seed,window", [(12, 26, 22, 1 << 22), (14, 28, 0, None), (16, 32, 0, 1 << 26), (18, 30, 5, 1 << 24)])
+def test_leaf_item_dealing_loses_nothing_under_repetition(ctx, m, n, seed, window):
+    """The leaf kernels deal their work items in runs that live in LDS and are emptied by compare-and-swap, and a
+    wave that finds the table dealt out takes what the other waves of its workgroup still hold (round 4).  A wave that
+    was told "nothing left" must stay out: a later, luckier draw used to lose the item behind it — two items in one
+    pass out of hundreds (found by test_prefix_level_kernels_agree[12-26-22]).  The same range many times over: the
+    three counts must add up to the range and never change, the optimum neither; once against the direct kernel."""
+    A, b, c, _ = lpcases.random_lp(seed, m, n)
+    total = o.binom(n, m)
+    lo = total // 7 if window else 0
+    hi = min(total, lo + window) if window else total
+    p = ctx.enum_problem(A, b, c, True)
+    ref = p.range(lo, hi, capi.ENUM_PREFIX)[:3]
+    assert sum(ref[2]) == hi - lo
+    if hi - lo <= (1 << 24):
+        assert p.range(lo, hi, capi.ENUM_DIRECT)[:3] == ref
+    for _ in range(40):
+        assert p.range(lo, hi, capi.ENUM_PREFIX)[:3] == ref
+    p.free()
