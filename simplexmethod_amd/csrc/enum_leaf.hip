@@ -1590,11 +1590,13 @@ int lp_enum_launch_leaves(lp_enum_problem* p, const double* roots, int bound, in
         LP_HIP(ctx, hipEventRecord(ctx->aux_event[0], s));          // the level records are complete
         LP_HIP(ctx, hipStreamWaitEvent(sT, ctx->aux_event[0], 0));
         // The thin kernel is latency-bound (8 lanes per record, gathers from HBM: half of its VALU slots idle) and
-        // nothing waits for it: a small grid of it (2 workgroups per CU, grid-stride) is queued BEHIND the item
+        // nothing waits for it: a small grid of it (ONE workgroup per CU, grid-stride) is queued BEHIND the item
         // builder, which is on the leaf kernels' critical path, and runs beside the leaf kernels.  (Launched first
         // with 12 workgroups per CU it held the chip while the item builder ran: 14.72 -> 14.50 ms on the whole
-        // range, 2.26 -> 2.21 ms on the slowest 8-way shard; scripts/time_enum_variant.py.)
-        const int thin_per_cu = 2;
+        // range, 2.26 -> 2.21 ms on the slowest 8-way shard.  Round 4, with the leaf kernels' new dealing: 1 / 2 / 3 / 4
+        // workgroups per CU 13.16 / 13.26 / 13.89 / 13.67 ms, slowest shard 1.92 / 1.95 / 2.01 / 1.99 ms — its waves
+        // hold slots that table 0's kernel, which ends the pass, would use better; scripts/time_enum_variant.py.)
+        const int thin_per_cu = 1;
         const unsigned grid_thin = (unsigned)std::min<uint64_t>(lp_ceil_div<uint64_t>((uint64_t)bound * 8, LEAF_THREADS), (uint64_t)ctx->num_cus * thin_per_cu);
         auto launch_thin = [&]() {
             if (exact)
